@@ -1,0 +1,244 @@
+/*
+ * vgen_hip.h — C ABI of libvgen_hip.so: the MI355X (gfx950) hot path of the VGen
+ * video-diffusion sampling loop (spatio-temporal UNet + AutoencoderKL + DDIM update).
+ *
+ * Boundary rules:
+ *   - plain C: raw device pointers, explicit sizes/strides, dtype enums, a hipStream_t
+ *     passed as void*.  No torch / C++ types in any signature.
+ *   - every function only ENQUEUES work on `stream`; it never allocates, frees or
+ *     synchronises.  The caller (PyTorch on the host side) owns every buffer.
+ *   - return value: 0 = ok, >0 = hipError_t of the failed launch, <0 = VGEN_E_* below.
+ *     vgen_last_error() returns a static human-readable string for the last failure.
+ *
+ * Canonical activation layout ("rows x channels", channels-last):
+ *   a video feature map [B, C, F, H, W] of the reference is held as a row-major matrix
+ *   [B*F*H*W, C]; row index m = ((b*F + f)*H + y)*W + x.  Spatial ops see B*F images,
+ *   temporal ops see F frames of S=H*W rows each — both are views of the same buffer,
+ *   so none of the reference's rearrange()/contiguous() copies exist here.
+ *   Residual streams are fp32; GEMM/conv operands are 16-bit (bf16 default, fp16 optional).
+ *
+ * Each entry point cites the reference call site it replaces (paths relative to the
+ * reference repo root).
+ */
+#ifndef VGEN_HIP_H
+#define VGEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VGEN_ABI_VERSION 1
+
+enum { VGEN_BF16 = 0, VGEN_F16 = 1, VGEN_F32 = 2 };
+
+enum {
+  VGEN_E_BADARG = -1,   /* shape / alignment / dtype constraint violated */
+  VGEN_E_UNSUPPORTED = -2,
+  VGEN_E_WORKSPACE = -3 /* caller-provided workspace too small */
+};
+
+int vgen_version(void);
+const char* vgen_last_error(void);
+
+/* ------------------------------------------------------------------------------------
+ * GroupNorm (+ optional SiLU), fp32 in -> 16-bit out.
+ * Replaces nn.GroupNorm(32, C)[+nn.SiLU] at tools/modules/unet/util.py:846,870 (ResBlock),
+ * :1663-1681 (TemporalConvBlock_v2, 5-D: statistics across all frames), :329 / :1211
+ * (Spatial/TemporalTransformer.norm, eps 1e-6, no SiLU), unet_t2v.py:205 (head) and
+ * Normalize()+nonlinearity() at tools/modules/autoencoder.py:11-16.
+ *
+ * Input rows are the virtual channel-concat of two sources (x2 may be NULL, C2 = 0):
+ *   row r = [ x1[r, 0:C1] | x2[r, 0:C2] ]  — this is how the decoder's
+ *   torch.cat([x, xs.pop()], 1) (unet_t2v.py:269) is consumed without materialising it.
+ * nb independent normalisation batches of S rows each (4-D GN: nb = B*F, S = H*W;
+ * 5-D GN: nb = B, S = F*H*W).  C = C1 + C2, C % (4*groups)... only C % 4 == 0 and
+ * C % groups == 0 are required; C <= 3072.
+ * y   : [nb*S, C] 16-bit, = act(gamma * (x - mean) * rstd + beta), act = SiLU if silu != 0
+ * raw : optional [nb*S, C] 16-bit plain cast of the concatenated input (feeds the 1x1
+ *       skip_connection conv, util.py:885); NULL to skip.
+ * ws  : fp32 scratch, at least vgen_groupnorm_ws_bytes(nb, S) bytes.
+ */
+size_t vgen_groupnorm_ws_bytes(int64_t nb, int64_t S);
+int vgen_groupnorm(const float* x1, int32_t C1, const float* x2, int32_t C2,
+                   int64_t nb, int64_t S, int32_t groups, float eps,
+                   const float* gamma, const float* beta, int32_t silu,
+                   void* y, void* raw, int32_t dtype,
+                   float* ws, size_t ws_bytes, void* stream);
+
+/* LayerNorm over the last dim, fp32 in -> 16-bit out (eps 1e-5 in the reference).
+ * Replaces nn.LayerNorm norm1/2/3 of BasicTransformerBlock (util.py:692-694,700-704).
+ * x [M, d] fp32 (row stride d), d % 4 == 0, d <= 2048. */
+int vgen_layernorm(const float* x, int64_t M, int32_t d, float eps,
+                   const float* gamma, const float* beta,
+                   void* y, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Tap-GEMM: the one MFMA contraction kernel behind every Linear / Conv1d(k=1) / Conv2d 1x1,
+ * Conv2d 3x3 (stride 1|2, optional folded nearest-2x upsample) and Conv3d (3,1,1).
+ *
+ *   out[m, n] = epi( sum_{tap} sum_{c<C1} A[src(m,tap), c] * W[n, tap*C1 + c]
+ *                  + sum_{c<C2} A2[m, c] * W[n, taps*C1 + c] )
+ *
+ * mode VGEN_TAP_LINEAR : taps = 1, src(m,0) = m.
+ *      nn.Linear at util.py:224-228 (to_q/k/v/out), :710 (GEGLU proj), :737 (FF out),
+ *      :337,351 (SpatialTransformer proj_in/out), unet_t2v.py:93-96 (time_embed),
+ *      util.py:862-868 (emb_layers); nn.Conv1d k=1 at util.py:1213,1229; 1x1 Conv2d at
+ *      util.py:885 and autoencoder.py:309,397-416.
+ * mode VGEN_TAP_CONV3X3: taps = 9 (ky*3+kx), rows m = (img*Ho + oy)*Wo + ox,
+ *      iy = oy*stride + ky - pad_t, ix = ox*stride + kx - pad_l over a (Hi<<ups)x(Wi<<ups)
+ *      virtual input whose pixel (iy,ix) is source pixel (iy>>ups, ix>>ups); out-of-range
+ *      taps contribute zero.  nn.Conv2d 3x3 at util.py:848,874 (ResBlock), :946 (Downsample,
+ *      stride 2 pad 1), :759+768 (Upsample: F.interpolate nearest x2 then conv),
+ *      unet_t2v.py:112,207; autoencoder.py:286,296 (ResnetBlock), :449-459 (Upsample),
+ *      :468-478 (Downsample: pad (0,1,0,1), stride 2 => pad_t = pad_l = 0).
+ * mode VGEN_TAP_TEMPORAL3: taps = 3 (kt), rows m = (b*F + f)*S + p, source frame f+kt-1
+ *      (zero outside [0,F)).  nn.Conv3d(C, C, (3,1,1), padding=(1,0,0)) at
+ *      util.py:1665,1670,1675,1680 (TemporalConvBlock_v2).
+ * The optional second K segment (A2, C2) with identity row mapping fuses the ResBlock's 1x1
+ * skip_connection (util.py:885,920) into the out-conv.
+ *
+ * Constraints: C1 % 64 == 0, C2 % 64 == 0, lda/lda2 % 8 == 0, 16-byte aligned pointers,
+ * ldw % 8 == 0.  A, A2, W are `dtype` (VGEN_BF16 | VGEN_F16);
+ * accumulation is fp32 on the MFMA units.
+ *
+ * Epilogue, applied in fp32 in this order:
+ *   v = acc + bias[n] + rowbias[(m / rows_per_rb) * rowbias_ld + n] + residual[m*ldr + n]
+ *   epilogue == VGEN_EPI_GEGLU: W rows are interleaved in blocks of 16 as
+ *       [16 value rows | 16 gate rows] (packed index pn; value j <-> rows 32*(j/16)+j%16,
+ *       gate j <-> +16), bias likewise; out[m, j] = v_value * gelu_erf(v_gate), j < N/2.
+ *       (GEGLU.forward, util.py:712-714.)
+ *   out is fp32 or 16-bit (out_dtype), row stride ldo.
+ */
+enum { VGEN_TAP_LINEAR = 0, VGEN_TAP_CONV3X3 = 1, VGEN_TAP_TEMPORAL3 = 2 };
+enum { VGEN_EPI_NONE = 0, VGEN_EPI_GEGLU = 1 };
+
+typedef struct vgen_tapgemm_args {
+  int64_t M;
+  int32_t N;
+  int32_t dtype;
+  const void* A;
+  int64_t lda;
+  int32_t C1;
+  int32_t taps;
+  int32_t mode;
+  int32_t Hi, Wi, Ho, Wo, stride, pad_t, pad_l, ups; /* CONV3X3 */
+  int32_t F;                                          /* TEMPORAL3 */
+  int64_t S;                                          /* TEMPORAL3: rows per frame */
+  const void* A2;
+  int64_t lda2;
+  int32_t C2;
+  const void* W;
+  int64_t ldw; /* W row stride in elements; 0 = dense (taps*C1 + C2) */
+  const float* bias;
+  const float* rowbias;
+  int64_t rowbias_ld;
+  int64_t rows_per_rb;
+  const float* residual;
+  int64_t ldr;
+  void* out;
+  int64_t ldo;
+  int32_t out_dtype;
+  int32_t epilogue;
+} vgen_tapgemm_args;
+
+int vgen_tapgemm(const vgen_tapgemm_args* args, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused attention, head_dim = 64, softmax(Q K^T * scale) V, no mask / dropout.
+ * Replaces xformers.ops.memory_efficient_attention at util.py:254-259 (the batch
+ * chunking at :248-257 is a workaround the fused kernel does not need).
+ *
+ * A "sequence" is identified by (batch index bi in [0,nbatch), head h in [0,heads)).
+ * Element (row r, head h, lane e) of tensor X lives at
+ *   X + (bi / inner) * X_bo + (bi % inner) * X_bi + r * X_rs + h*64 + e
+ * which expresses, without copies:
+ *   spatial self-attn   : bi = image, rows = pixels            (inner = 1)
+ *   spatial cross-attn  : q as above; k/v = per-prompt context (inner = F, k_bi = 0)
+ *   temporal self-attn  : bi = (b, pixel), rows = frames, row stride = H*W*ld (inner = H*W)
+ * nq <= 16 && nk <= 16 selects the one-wave-per-sequence temporal kernel.
+ */
+typedef struct vgen_attn_args {
+  const void* q;
+  const void* k;
+  const void* v;
+  void* out;
+  int32_t dtype;
+  int32_t heads;
+  int32_t nq, nk;
+  int64_t nbatch;
+  int64_t inner;
+  int64_t q_rs, q_bo, q_bi;
+  int64_t k_rs, k_bo, k_bi;
+  int64_t v_rs, v_bo, v_bi;
+  int64_t o_rs, o_bo, o_bi;
+  float scale;
+} vgen_attn_args;
+
+int vgen_attention(const vgen_attn_args* args, void* stream);
+
+/* Row softmax: P[r, :] = softmax(S[r, :] * scale), fp32 in -> 16-bit out.
+ * Single-head 512-channel VAE attention, autoencoder.py:430-437 (bmm, scale, softmax). */
+int vgen_softmax_rows(const float* S, int64_t rows, int32_t cols, int64_t lds, float scale,
+                      void* P, int64_t ldp, int32_t dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Small elementwise / layout kernels.
+ */
+
+/* y = act(x) cast to 16-bit; act: 0 = identity, 1 = SiLU.  (nn.SiLU in time_embed /
+ * emb_layers, unet_t2v.py:94, util.py:863.) */
+int vgen_act_cast(const float* x, void* y, int64_t n, int32_t act, int32_t dtype, void* stream);
+
+/* sinusoidal_embedding (util.py:178-190): out[b, :] = [cos(t_b * w_i) | sin(t_b * w_i)],
+ * w_i = 10000^(-i/half), 16-bit out.  t is fp32 [B]. */
+int vgen_timestep_embedding(const float* t, int32_t B, int32_t dim, void* out, int32_t dtype,
+                            void* stream);
+
+/* im2col of a small-channel 3x3/pad-1/stride-1 conv into a [M, Kpad] 16-bit matrix
+ * (Kpad % 64 == 0, columns (ky*3+kx)*Cin + c, zero padded), so that the 4->320 input conv
+ * (unet_t2v.py:112) and the VAE conv_in (autoencoder.py:605) run on the tap-GEMM.
+ * Source element (img = bo*Fi + fi, c, y, x) at src + bo*s_bo + fi*s_fi + c*s_c + y*s_y + x*s_x
+ * (fp32) — covers both [B,C,F,H,W] latents and [N,H,W,C] maps. */
+int vgen_im2col3x3_small(const float* src, int64_t nimg, int32_t Fi, int32_t Cin, int32_t H,
+                         int32_t W, int64_t s_bo, int64_t s_fi, int64_t s_c, int64_t s_y,
+                         int64_t s_x, void* out, int32_t Kpad, int32_t dtype, void* stream);
+
+/* out[p, co] = sum_ci Wm[co, ci] * in[p, ci] + b[co], tiny channel counts (<= 16), fp32.
+ * Source/destination addressed with the same (bo, fi, c, y, x) strides as above so the op
+ * doubles as a layout change (post_quant_conv / quant_conv 1x1, autoencoder.py:50-51,
+ * NCHW<->rows).  */
+int vgen_pointwise_small(const float* src, int64_t nimg, int32_t Fi, int32_t Cin, int32_t H,
+                         int32_t W, int64_t s_bo, int64_t s_fi, int64_t s_c, int64_t s_y,
+                         int64_t s_x, const float* Wm, const float* b, int32_t Cout, float* dst,
+                         int64_t d_bo, int64_t d_fi, int64_t d_c, int64_t d_y, int64_t d_x,
+                         void* stream);
+
+/* Fused classifier-free-guidance combine + DDIM update on the fp32 latent, replicating the
+ * arithmetic ORDER of DiffusionDDIM.p_mean_variance / ddim_sample
+ * (tools/modules/diffusions/diffusion_ddim.py:157-162, 194-197, 230-240) op for op in
+ * fp32 without FMA contraction, for mean_type in {eps, v, x0}:
+ *   out  = u + g*(y - u)                     (guide != 0; else out = y)
+ *   x0   = c[0]*xt - c[1]*out  (v)  |  c[0]*xt - c[1]*out (eps, other coefs) | out (x0)
+ *   eps  = (c[2]*xt - x0) / c[3]
+ *   xt_1 = sqrt(c[4])*x0 + sqrt(1 - c[4] - c[5]^2)*eps + c[6]*c[5]*noise
+ * coef = 7 fp32 per batch element b: [a0, a1, sqrt_recip, sqrt_recipm1, alpha_prev, sigma, mask].
+ * All tensors contiguous fp32 with `per_b` elements per batch element; noise may be NULL
+ * when every sigma is 0.  mean_type: 0 = eps, 1 = v, 2 = x0. */
+int vgen_cfg_ddim_step(const float* xt, const float* y, const float* u, const float* noise,
+                       const float* coef, float guide, int32_t use_guide, int32_t mean_type,
+                       int64_t B, int64_t per_b, float* xt_1, float* x0_out, void* stream);
+
+/* DiagonalGaussianDistribution.sample() * scale (autoencoder.py:212-225, 19-27):
+ * moments rows [P, 2*zc] fp32 (mean | logvar), logvar clamped to [-30, 20],
+ * z = (mean + exp(0.5*logvar) * noise) * scale written as [nimg, zc, H, W] fp32;
+ * noise has the output layout. */
+int vgen_gaussian_sample(const float* moments, const float* noise, int64_t nimg, int32_t zc,
+                         int64_t HW, float scale, float* z, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VGEN_HIP_H */

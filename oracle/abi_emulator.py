@@ -1,0 +1,185 @@
+"""TEST INFRASTRUCTURE — CPU emulation of the libvgen_hip.so C ABI (include/vgen_hip.h).
+
+Implements the same op set as vgen_amd.ops.HipBackend in plain torch so the test-suite can run
+the HOST logic (weight packing, layouts, strides, call order of vgen_amd.unet / vae / diffusion)
+on CPU against the reference.  Each method follows the semantics written in the header — row
+gathers, packed weight layouts, strided sequences — not the structure of the reference model.
+16-bit rounding points are reproduced (operands are rounded to `dt`, accumulation in fp32).
+
+Never imported by product code: tests install it with `vgen_amd.ops.set_backend(EmuBackend())`.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from vgen_amd import lib as L
+
+
+def _strided(t, sizes, strides):
+    return torch.as_strided(t, sizes, strides, t.storage_offset())
+
+
+class EmuBackend:
+    name = "emu"
+
+    # -- norms ---------------------------------------------------------------------------------
+    def groupnorm(self, x1, x2, nb, S, groups, eps, gamma, beta, silu, want_raw, dt):
+        x = x1 if x2 is None else torch.cat([x1, x2], 1)
+        C = x.shape[1]
+        assert C % 4 == 0 and C % groups == 0 and x1.shape[1] % 4 == 0
+        v = x.view(nb, S, groups, C // groups).float()
+        mean = v.mean(dim=(1, 3), keepdim=True)
+        var = v.var(dim=(1, 3), unbiased=False, keepdim=True)
+        y = ((v - mean) / torch.sqrt(var + eps)).view(nb * S, C) * gamma + beta
+        if silu:
+            y = y * torch.sigmoid(y)
+        return y.to(dt), (x.to(dt) if want_raw else None)
+
+    def layernorm(self, x, gamma, beta, eps, dt):
+        mean = x.mean(-1, keepdim=True)
+        var = x.var(-1, unbiased=False, keepdim=True)
+        return (((x - mean) / torch.sqrt(var + eps)) * gamma + beta).to(dt)
+
+    # -- tap GEMM --------------------------------------------------------------------------------
+    @staticmethod
+    def _src_rows(g):
+        m = torch.arange(g.M)
+        rows = []
+        if g.mode == L.TAP_LINEAR:
+            rows.append(m)
+        elif g.mode == L.TAP_CONV3X3:
+            hw = g.Ho * g.Wo
+            img, rem = m // hw, m % hw
+            oy, ox = rem // g.Wo, rem % g.Wo
+            Hv, Wv = g.Hi << g.ups, g.Wi << g.ups
+            for tap in range(9):
+                iy = oy * g.stride + tap // 3 - g.pad_t
+                ix = ox * g.stride + tap % 3 - g.pad_l
+                ok = (iy >= 0) & (iy < Hv) & (ix >= 0) & (ix < Wv)
+                r = img * g.Hi * g.Wi + (iy >> g.ups) * g.Wi + (ix >> g.ups)
+                rows.append(torch.where(ok, r, torch.full_like(r, -1)))
+        elif g.mode == L.TAP_TEMPORAL3:
+            f = (m // g.S) % g.F
+            for tap in range(3):
+                f2 = f + tap - 1
+                ok = (f2 >= 0) & (f2 < g.F)
+                rows.append(torch.where(ok, m + (tap - 1) * g.S, torch.full_like(m, -1)))
+        else:
+            raise ValueError(g.mode)
+        return rows
+
+    def tapgemm(self, g):
+        assert g.C1 % 64 == 0 and g.C2 % 64 == 0
+        assert g.A.stride(1) == 1 and g.A.stride(0) % 8 == 0
+        dt = g.A.dtype
+        assert dt in (torch.bfloat16, torch.float16) and g.W.dtype == dt
+        K = g.taps * g.C1 + g.C2
+        W = g.W[: g.N, :K].float()
+        acc = torch.zeros((g.M, g.N), dtype=torch.float32)
+        for tap, r in enumerate(self._src_rows(g)):
+            a = g.A[:, : g.C1][r.clamp(min=0)].float()
+            a = torch.where((r >= 0)[:, None], a, torch.zeros_like(a))
+            acc += a @ W[:, tap * g.C1:(tap + 1) * g.C1].t()
+        if g.C2:
+            assert g.A2.dtype == dt
+            acc += g.A2[: g.M, : g.C2].float() @ W[:, g.taps * g.C1:].t()
+        if g.bias is not None:
+            acc += g.bias[: g.N]
+        if g.rowbias is not None:
+            idx = torch.arange(g.M) // g.rows_per_rb
+            acc += g.rowbias[idx][:, : g.N]
+        if g.epilogue == L.EPI_GEGLU:
+            assert g.N % 64 == 0 and g.rowbias is None
+            v = acc.view(g.M, g.N // 32, 2, 16)
+            val, gate = v[:, :, 0], v[:, :, 1]
+            acc = (val * (0.5 * gate * (1.0 + torch.erf(gate * 0.7071067811865476)))).reshape(g.M, g.N // 2)
+            n_out = g.N // 2
+        else:
+            n_out = g.N
+        if g.residual is not None:
+            acc += g.residual[:, :n_out]
+        out = g.out
+        if out is None:
+            out = torch.empty((g.M, n_out), dtype=g.out_dtype)
+        assert out.dtype == g.out_dtype and out.dtype in (torch.float32, dt)
+        out[:, :n_out] = acc.to(g.out_dtype)
+        return out
+
+    # -- attention -------------------------------------------------------------------------------
+    def attention(self, g):
+        assert g.nbatch % g.inner == 0
+        no, ni = g.nbatch // g.inner, g.inner
+
+        def seqs(t, s, n):
+            rs, bo, bi = s
+            return _strided(t, (no, ni, g.heads, n, 64), (bo, bi, 64, rs, 1)).float()
+
+        q, k, v = seqs(g.q, g.q_s, g.nq), seqs(g.k, g.k_s, g.nk), seqs(g.v, g.v_s, g.nk)
+        w = torch.softmax(q @ k.transpose(-1, -2) * g.scale, dim=-1)
+        o = w @ v
+        rs, bo, bi = g.o_s
+        _strided(g.out, (no, ni, g.heads, g.nq, 64), (bo, bi, 64, rs, 1)).copy_(o.to(g.out.dtype))
+        return g.out
+
+    def softmax_rows(self, S, cols, scale, dt, out=None):
+        p = torch.softmax(S[:, :cols].float() * scale, dim=-1).to(dt)
+        if out is None:
+            return p
+        out[:, :cols] = p
+        return out
+
+    # -- small kernels ---------------------------------------------------------------------------
+    def act_cast(self, x, act, dt):
+        return (x * torch.sigmoid(x) if act == 1 else x).to(dt)
+
+    def timestep_embedding(self, t, dim, dt):
+        half = dim // 2
+        w = torch.pow(torch.tensor(10000.0), -(torch.arange(half).float() / half))
+        a = t[:, None] * w[None, :]
+        e = torch.cat([torch.cos(a), torch.sin(a)], 1)
+        if dim % 2:
+            e = torch.cat([e, torch.zeros_like(e[:, :1])], 1)
+        return e.to(dt)
+
+    @staticmethod
+    def _view5(t, nimg, Fi, C, H, W, s):
+        s_bo, s_fi, s_c, s_y, s_x = s
+        return _strided(t, (nimg // Fi, Fi, C, H, W), (s_bo, s_fi, s_c, s_y, s_x))
+
+    def im2col3x3_small(self, src, nimg, Fi, Cin, H, W, strides, Kpad, dt):
+        x = self._view5(src, nimg, Fi, Cin, H, W, strides).reshape(nimg, Cin, H, W)
+        xp = torch.nn.functional.pad(x, (1, 1, 1, 1))
+        out = torch.zeros((nimg, H, W, Kpad), dtype=torch.float32)
+        for tap in range(9):
+            ky, kx = tap // 3, tap % 3
+            out[..., tap * Cin:(tap + 1) * Cin] = xp[:, :, ky:ky + H, kx:kx + W].permute(0, 2, 3, 1)
+        return out.reshape(nimg * H * W, Kpad).to(dt)
+
+    def pointwise_small(self, src, nimg, Fi, Cin, H, W, s_strides, Wm, b, Cout, dst, d_strides):
+        x = self._view5(src, nimg, Fi, Cin, H, W, s_strides)
+        o = torch.einsum("oc,bfchw->bfohw", Wm, x)
+        if b is not None:
+            o = o + b.view(1, 1, -1, 1, 1)
+        self._view5(dst, nimg, Fi, Cout, H, W, d_strides).copy_(o)
+        return dst
+
+    def cfg_ddim_step(self, xt, y, u, noise, coef, guide, use_guide, mean_type, want_x0):
+        shape = (xt.shape[0],) + (1,) * (xt.ndim - 1)
+        c = [coef[:, i].view(shape) for i in range(7)]
+        out = y
+        if use_guide:
+            out = u + torch.tensor(guide, dtype=torch.float32) * (y - u)
+        x0 = out if mean_type == 2 else c[0] * xt - c[1] * out
+        eps = (c[2] * xt - x0) / c[3]
+        r = torch.sqrt(c[4]) * x0 + torch.sqrt(1.0 - c[4] - c[5] * c[5]) * eps
+        if noise is not None:
+            r = r + c[6] * c[5] * noise
+        return r, (x0.clone() if want_x0 else None)
+
+    def gaussian_sample(self, moments, noise, nimg, zc, HW, scale):
+        m = moments.view(nimg, HW, 2 * zc)
+        mean = m[..., :zc].permute(0, 2, 1).reshape(noise.shape)
+        logvar = m[..., zc:].permute(0, 2, 1).reshape(noise.shape).clamp(-30.0, 20.0)
+        return scale * (mean + torch.exp(0.5 * logvar) * noise)

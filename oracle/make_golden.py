@@ -1,0 +1,155 @@
+"""TEST INFRASTRUCTURE — generates tests/golden/*.pt by running the REFERENCE's own modules
+(imported from /root/reference via oracle/ref_import.py) on seeded synthetic weights/inputs.
+
+The reference has no golden vectors of its own; these fixtures are what pins the
+oracle (oracle/torch_ref.py) and the HIP path on the GPU box, where the reference tree does not
+exist.  Weights are NOT stored: they are regenerated from `seed` by torch_ref.synth_state_dict
+(deterministic CPU generator over the stored key/shape list).
+
+    python -m oracle.make_golden            # tiny fixtures (seconds)
+    python -m oracle.make_golden --full     # + full-size UNet forward / VAE frame (minutes, ~12 GB RAM)
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import ref_import, torch_ref  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+UNET_TINY = dict(in_dim=4, dim=64, y_dim=1024, context_dim=1024, out_dim=4, dim_mult=[1, 2, 4],
+                 num_heads=2, head_dim=64, num_res_blocks=1, attn_scales=[1.0, 0.5, 0.25], dropout=0.1,
+                 temporal_attention=True, temporal_attn_times=1, use_checkpoint=False,
+                 use_fps_condition=False, use_sim_mask=False)
+# configs/t2v_train.yaml:32-51 over tools/modules/config.py:96-114
+UNET_T2V = dict(in_dim=4, dim=320, y_dim=1024, context_dim=1024, out_dim=4, dim_mult=[1, 2, 4, 4],
+                num_heads=8, head_dim=64, num_res_blocks=2, attn_scales=[1.0, 0.5, 0.25], dropout=0.1,
+                temporal_attention=True, temporal_attn_times=1, use_checkpoint=False,
+                use_fps_condition=False, use_sim_mask=False)
+VAE_TINY = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=64,
+                ch_mult=[1, 2, 4, 4], num_res_blocks=1, attn_resolutions=[], dropout=0.0)
+# tools/modules/config.py:118-135
+VAE_SD = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128,
+              ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0,
+              video_kernel_size=[3, 1, 1])
+DDIM_T2V = dict(schedule="cosine", schedule_param=dict(num_timesteps=1000, cosine_s=0.008, zero_terminal_snr=True),
+                mean_type="v", loss_type="mse", var_type="fixed_small", rescale_timesteps=False,
+                noise_strength=0.1)
+
+
+def _inputs(seed, B, F, H, W, L=77, ctx=1024):
+    g = torch.Generator("cpu").manual_seed(seed)
+    x = torch.randn(B, 4, F, H, W, generator=g)
+    y = torch.randn(B, L, ctx, generator=g)
+    return x, y
+
+
+def dummy_model(x, t, y=None, **kw):
+    """Cheap deterministic stand-in for the UNet in sampler fixtures."""
+    w = torch.tensor([[0.6, -0.2, 0.1, 0.0], [0.1, 0.5, -0.3, 0.2], [-0.2, 0.1, 0.7, 0.1], [0.0, 0.3, -0.1, 0.4]])
+    return torch.einsum("oc,bcfhw->bofhw", w.to(x), x) + 0.05 * y.float().mean() \
+        + 0.001 * t.float().view(-1, 1, 1, 1, 1)
+
+
+@torch.no_grad()
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--full", action="store_true")
+    args = ap.parse_args()
+    os.makedirs(GOLD, exist_ok=True)
+    R = ref_import.load()
+    torch.manual_seed(0)
+
+    # ---- schedules + sampler --------------------------------------------------------------
+    rs = R["schedules"]
+    sched = {
+        "cosine_zts": rs.beta_schedule("cosine", 1000, zero_terminal_snr=True, cosine_s=0.008),
+        "linear_sd_zts": rs.beta_schedule("linear_sd", 1000, zero_terminal_snr=True, init_beta=0.00085, last_beta=0.012),
+        "quadratic": rs.beta_schedule("quadratic", 1000, init_beta=None, last_beta=None),
+        "sigma_logsnr_cosine_interp_zts": rs.sigma_schedule("logsnr_cosine_interp", 1000, zero_terminal_snr=True,
+                                                            scale_min=2.0, scale_max=4.0, logsnr_min=-15.0, logsnr_max=15.0),
+        "sigma_cosine_zts": rs.sigma_schedule("cosine", 1000, zero_terminal_snr=True, cosine_s=0.008),
+    }
+    diff = R["DIFFUSION"].build(dict(type="DiffusionDDIM", **DDIM_T2V))
+    g = torch.Generator("cpu").manual_seed(11)
+    noise = torch.randn(2, 4, 4, 8, 8, generator=g)
+    kw = [dict(y=torch.randn(2, 77, 16, generator=g)), dict(y=torch.randn(2, 77, 16, generator=g))]
+    out50 = diff.ddim_sample_loop(noise.clone(), dummy_model, kw, guide_scale=9.0, ddim_timesteps=50, eta=0.0)
+    x0 = torch.randn(2, 4, 4, 8, 8, generator=g)
+    inv20 = diff.ddim_reverse_sample_loop(x0.clone(), dummy_model, kw[0], guide_scale=None, ddim_timesteps=20)
+    t = torch.tensor([981, 21])
+    xt1, x0p = diff.ddim_sample(noise.clone(), t, dummy_model, kw, guide_scale=9.0, ddim_timesteps=50, eta=0.0)
+    torch.save(dict(schedules=sched, cfg=DDIM_T2V, noise=noise, kw=kw, out50=out50, x0=x0, inv20=inv20,
+                    step_t=t, step_xt1=xt1, step_x0=x0p,
+                    tables=dict(alphas_cumprod=diff.alphas_cumprod, sqrt_recipm1=diff.sqrt_recipm1_alphas_cumprod)),
+               os.path.join(GOLD, "ddim.pt"))
+
+    # ---- tiny UNet ---------------------------------------------------------------------------
+    ref = R["MODEL"].build(dict(type="UNetSD_T2VBase", **UNET_TINY)).eval()
+    shapes = torch_ref.shapes_of(ref)
+    sd = torch_ref.synth_state_dict(shapes, seed=1)
+    ref.load_state_dict(sd, strict=True)
+    x, y = _inputs(5, 2, 4, 16, 8)
+    t = torch.tensor([981, 401])
+    out = ref(x, t, y=y)
+    torch.save(dict(cfg=UNET_TINY, seed=1, shapes=shapes, x=x, t=t, y=y, out=out),
+               os.path.join(GOLD, "unet_tiny.pt"))
+    print("unet_tiny", tuple(out.shape), float(out.std()))
+
+    # ---- tiny VAE ------------------------------------------------------------------------------
+    vae = R["AUTO_ENCODER"].build(dict(type="AutoencoderKL", ddconfig=VAE_TINY, embed_dim=4)).eval()
+    vshapes = torch_ref.shapes_of(vae)
+    vsd = torch_ref.synth_state_dict(vshapes, seed=2)
+    vae.load_state_dict(vsd, strict=True)
+    g = torch.Generator("cpu").manual_seed(6)
+    z = torch.randn(2, 4, 8, 16, generator=g)
+    img = torch.randn(2, 3, 64, 32, generator=g)
+    dec = vae.decode(z)
+    mom = vae.encode(img).parameters
+    torch.manual_seed(3)
+    zs = vae.encode_firsr_stage(img, 0.18215)
+    torch.save(dict(ddconfig=VAE_TINY, seed=2, shapes=vshapes, z=z, img=img, dec=dec, moments=mom,
+                    sample_seed=3, z_sample=zs), os.path.join(GOLD, "vae_tiny.pt"))
+    print("vae_tiny", tuple(dec.shape), float(dec.std()))
+
+    if args.full:
+        # ---- full-size t2v UNet forward (config 2 of BASELINE.json), B = 1 ----------------------
+        import time
+        ref = R["MODEL"].build(dict(type="UNetSD_T2VBase", **UNET_T2V)).eval()
+        shapes = torch_ref.shapes_of(ref)
+        sd = torch_ref.synth_state_dict(shapes, seed=0)
+        ref.load_state_dict(sd, strict=True)
+        del sd
+        g = torch.Generator("cpu").manual_seed(8888)          # cfg seed, t2v_infer.yaml:14
+        x = torch.randn(1, 4, 16, 32, 56, generator=g)
+        y = torch.randn(1, 77, 1024, generator=g)
+        t = torch.tensor([981])
+        t0 = time.time()
+        out = ref(x, t, y=y)
+        print("unet_t2v full forward: %.1f s, std %.4f" % (time.time() - t0, float(out.std())))
+        torch.save(dict(cfg=UNET_T2V, seed=0, shapes=shapes, input_seed=8888, t=t, out=out,
+                        out_norm=float(out.norm())), os.path.join(GOLD, "unet_t2v_full.pt"))
+        del ref
+        vae = R["AUTO_ENCODER"].build(dict(type="AutoencoderKL", ddconfig=VAE_SD, embed_dim=4)).eval()
+        vshapes = torch_ref.shapes_of(vae)
+        vae.load_state_dict(torch_ref.synth_state_dict(vshapes, seed=0), strict=True)
+        g = torch.Generator("cpu").manual_seed(8889)
+        z = torch.randn(1, 4, 32, 56, generator=g)
+        t0 = time.time()
+        dec = vae.decode(z)
+        print("vae full decode: %.1f s" % (time.time() - t0))
+        # keep the fixture small: store a strided sub-sample + norms
+        torch.save(dict(ddconfig=VAE_SD, seed=0, shapes=vshapes, input_seed=8889,
+                        dec_sub=dec[:, :, ::4, ::4].contiguous(), dec_norm=float(dec.norm())),
+                   os.path.join(GOLD, "vae_sd_full.pt"))
+
+
+if __name__ == "__main__":
+    main()

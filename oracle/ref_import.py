@@ -1,0 +1,73 @@
+"""TEST INFRASTRUCTURE — loads the reference's own modules (read-only tree at /root/reference)
+on CPU so the restatement in oracle/torch_ref.py and the golden fixtures can be pinned against
+the real thing.  Only usable in the build container (the GPU box has no /root/reference);
+nothing under vgen_amd/ imports this file.
+
+Recipe = SURVEY.md Appendix C: four stub modules for un-vendored third-party deps
+(xformers.ops.memory_efficient_attention restated as softmax(q k^T / sqrt(d)) v via
+F.scaled_dot_product_attention — xformers==0.0.13 is pinned in the reference's requirements.txt
+but is absent here), bare package objects so `tools/__init__.py` (cv2, open_clip, ...) is skipped,
+and the leaf files loaded by path.
+"""
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+import types
+
+REF = os.environ.get("VGEN_REFERENCE", "/root/reference")
+
+
+def available() -> bool:
+    return os.path.isdir(os.path.join(REF, "tools", "modules"))
+
+
+_loaded = {}
+
+
+def load():
+    """Returns dict(MODEL=..., AUTO_ENCODER=..., DIFFUSION=..., util=<module>, ...)."""
+    if _loaded:
+        return _loaded
+    if not available():
+        raise RuntimeError(f"reference tree not found at {REF}")
+    import torch.nn.functional as F
+
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    xf, xo = types.ModuleType("xformers"), types.ModuleType("xformers.ops")
+    xo.memory_efficient_attention = lambda q, k, v, attn_bias=None, op=None: \
+        F.scaled_dot_product_attention(q, k, v)
+    xo.LowerTriangularMask = type("LowerTriangularMask", (), {})
+    xf.ops = xo
+    sys.modules.update({"xformers": xf, "xformers.ops": xo, "open_clip": types.ModuleType("open_clip")})
+    r = types.ModuleType("rotary_embedding_torch")
+    r.RotaryEmbedding = object
+    sys.modules["rotary_embedding_torch"] = r
+    fc = types.ModuleType("fairscale.nn.checkpoint")
+    fc.checkpoint_wrapper = lambda m, *a, **k: m
+    sys.modules.update({"fairscale": types.ModuleType("fairscale"),
+                        "fairscale.nn": types.ModuleType("fairscale.nn"),
+                        "fairscale.nn.checkpoint": fc})
+    for pkg in ("tools", "tools.modules", "tools.modules.unet", "tools.modules.diffusions"):
+        m = types.ModuleType(pkg)
+        m.__path__ = [os.path.join(REF, pkg.replace(".", "/"))]
+        sys.modules[pkg] = m
+
+    def _load(name):
+        spec = importlib.util.spec_from_file_location(name, os.path.join(REF, name.replace(".", "/") + ".py"))
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+
+    mods = {}
+    for n in ("tools.modules.unet.util", "tools.modules.unet.unet_t2v", "tools.modules.autoencoder",
+              "tools.modules.diffusions.schedules", "tools.modules.diffusions.losses",
+              "tools.modules.diffusions.diffusion_ddim"):
+        mods[n.rsplit(".", 1)[-1]] = _load(n)
+    from utils.registry_class import AUTO_ENCODER, DIFFUSION, MODEL
+    _loaded.update(mods)
+    _loaded.update(MODEL=MODEL, AUTO_ENCODER=AUTO_ENCODER, DIFFUSION=DIFFUSION)
+    return _loaded

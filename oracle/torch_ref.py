@@ -1,0 +1,370 @@
+"""TEST INFRASTRUCTURE (oracle) — CPU restatement, in plain fp32 torch, of the reference's
+algorithm for the sampling hot path.  Functional style over a state_dict with the reference's key
+names; every function cites the reference file:line it follows (paths relative to the reference
+root).  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+
+PARITY PIN: the reference ships no golden vectors / tests for this path, so the
+oracle is pinned against the reference's OWN modules executed on CPU in the build container
+(oracle/ref_import.py): tests/test_oracle_vs_reference.py checks every function here against
+them, and oracle/make_golden.py stores reference-generated fixtures under tests/golden/ that
+travel to the GPU box.  Third-party arithmetic restated mathematically (not pinned by any
+reference test): xformers.ops.memory_efficient_attention (xformers==0.0.13) = softmax(QK^T/sqrt(d))V.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn.functional as F
+
+# ------------------------------------------------------------------------------------------
+# deterministic synthetic weights (pretrained checkpoints are not available offline)
+# ------------------------------------------------------------------------------------------
+
+
+def synth_state_dict(shapes: dict, seed: int = 0, gain: float = 0.8) -> dict:
+    """Seeded re-randomisation of EVERY parameter (the reference zero-initialises the ResBlock
+    out-conv, temporal conv4, proj_out, head conv — util.py:873-875,1683-1684,351,1229,
+    unet_t2v.py:208 — which would make a parity check vacuous; SURVEY.md §8c "Trap").
+    >=2-D weights ~ N(0, gain/sqrt(fan_in)), norm scales ~ 1 + 0.1 N, biases ~ 0.1 N.
+    Keys are visited in sorted order with one CPU generator, so any process that knows the
+    shapes reproduces the same tensors."""
+    g = torch.Generator("cpu").manual_seed(seed)
+    sd = {}
+    for k in sorted(shapes):
+        shp = tuple(shapes[k])
+        if len(shp) >= 2:
+            fan_in = 1
+            for s in shp[1:]:
+                fan_in *= s
+            sd[k] = torch.randn(shp, generator=g) * (gain / math.sqrt(fan_in))
+        elif k.endswith("weight"):
+            sd[k] = 1.0 + 0.1 * torch.randn(shp, generator=g)
+        else:
+            sd[k] = 0.1 * torch.randn(shp, generator=g)
+    return sd
+
+
+def shapes_of(module) -> dict:
+    return {k: tuple(v.shape) for k, v in module.state_dict().items()}
+
+
+# ------------------------------------------------------------------------------------------
+# UNet blocks
+# ------------------------------------------------------------------------------------------
+
+
+def sinusoidal_embedding(timesteps, dim):
+    # unet/util.py:178-190
+    half = dim // 2
+    timesteps = timesteps.float()
+    freqs = torch.pow(10000, -torch.arange(half).to(timesteps).div(half))
+    s = torch.outer(timesteps, freqs)
+    x = torch.cat([torch.cos(s), torch.sin(s)], dim=1)
+    if dim % 2 != 0:
+        x = torch.cat([x, torch.zeros_like(x[:, :1])], dim=1)
+    return x
+
+
+def _gn(sd, p, x, eps):
+    return F.group_norm(x, 32, sd[p + ".weight"], sd[p + ".bias"], eps)
+
+
+def attention(sd, p, x, context, heads):
+    # MemoryEfficientCrossAttention.forward, unet/util.py:231-269: q/k/v Linear (no bias),
+    # heads split to [B*h, M, 64], softmax(q k^T * 64^-0.5) v, merge heads, to_out Linear.
+    ctx = x if context is None else context
+    q = F.linear(x, sd[p + ".to_q.weight"])
+    k = F.linear(ctx, sd[p + ".to_k.weight"])
+    v = F.linear(ctx, sd[p + ".to_v.weight"])
+    b, n, _ = q.shape
+    d = q.shape[-1] // heads
+
+    def split(t):
+        return t.reshape(b, t.shape[1], heads, d).permute(0, 2, 1, 3)
+
+    q, k, v = split(q), split(k), split(v)
+    w = torch.softmax(q @ k.transpose(-1, -2) * (d ** -0.5), dim=-1)
+    o = (w @ v).permute(0, 2, 1, 3).reshape(b, n, heads * d)
+    return F.linear(o, sd[p + ".to_out.0.weight"], sd[p + ".to_out.0.bias"])
+
+
+def transformer_block(sd, p, x, context, heads):
+    # BasicTransformerBlock.forward, unet/util.py:700-704; GEGLU :712-714; FeedForward :724-741
+    def ln(i, t):
+        return F.layer_norm(t, (t.shape[-1],), sd[f"{p}.norm{i}.weight"], sd[f"{p}.norm{i}.bias"], 1e-5)
+
+    x = attention(sd, p + ".attn1", ln(1, x), None, heads) + x
+    x = attention(sd, p + ".attn2", ln(2, x), context, heads) + x
+    h = F.linear(ln(3, x), sd[p + ".ff.net.0.proj.weight"], sd[p + ".ff.net.0.proj.bias"])
+    a, gate = h.chunk(2, dim=-1)
+    h = a * F.gelu(gate)
+    return F.linear(h, sd[p + ".ff.net.2.weight"], sd[p + ".ff.net.2.bias"]) + x
+
+
+def spatial_transformer(sd, p, x, context):
+    # SpatialTransformer.forward (use_linear=True), unet/util.py:354-373
+    b, c, h, w = x.shape
+    inner = sd[p + ".proj_in.weight"].shape[0]
+    t = _gn(sd, p + ".norm", x, 1e-6)
+    t = t.permute(0, 2, 3, 1).reshape(b, h * w, c)
+    t = F.linear(t, sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"])
+    t = transformer_block(sd, p + ".transformer_blocks.0", t, context, inner // 64)
+    t = F.linear(t, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"])
+    return t.reshape(b, h, w, c).permute(0, 3, 1, 2) + x
+
+
+def temporal_transformer(sd, p, x):
+    # TemporalTransformer.forward (use_linear=False, only_self_att=True), unet/util.py:1240-1286:
+    # GN over the 5-D tensor, tokens = frames of one pixel, both attentions are self-attention.
+    b, c, f, h, w = x.shape
+    inner = sd[p + ".proj_in.weight"].shape[0]
+    t = _gn(sd, p + ".norm", x, 1e-6)
+    t = t.permute(0, 3, 4, 1, 2).reshape(b * h * w, c, f)
+    t = F.conv1d(t, sd[p + ".proj_in.weight"], sd[p + ".proj_in.bias"])
+    t = t.permute(0, 2, 1)
+    t = transformer_block(sd, p + ".transformer_blocks.0", t, None, inner // 64)
+    t = t.permute(0, 2, 1)
+    t = F.conv1d(t, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"])
+    return t.reshape(b, h, w, c, f).permute(0, 3, 4, 1, 2) + x
+
+
+def temporal_conv_block(sd, p, x):
+    # TemporalConvBlock_v2.forward, unet/util.py:1686-1697 (dropout inactive in eval)
+    h = x
+    for i in (1, 2, 3, 4):
+        ci = 2 if i == 1 else 3
+        h = F.silu(_gn(sd, f"{p}.conv{i}.0", h, 1e-5))
+        h = F.conv3d(h, sd[f"{p}.conv{i}.{ci}.weight"], sd[f"{p}.conv{i}.{ci}.bias"], padding=(1, 0, 0))
+    return x + h
+
+
+def resblock(sd, p, x, emb, batch):
+    # ResBlock._forward, unet/util.py:900-927 (use_scale_shift_norm False, no up/down)
+    h = F.conv2d(F.silu(_gn(sd, p + ".in_layers.0", x, 1e-5)), sd[p + ".in_layers.2.weight"],
+                 sd[p + ".in_layers.2.bias"], padding=1)
+    e = F.linear(F.silu(emb), sd[p + ".emb_layers.1.weight"], sd[p + ".emb_layers.1.bias"])
+    h = h + e[:, :, None, None]
+    h = F.conv2d(F.silu(_gn(sd, p + ".out_layers.0", h, 1e-5)), sd[p + ".out_layers.3.weight"],
+                 sd[p + ".out_layers.3.bias"], padding=1)
+    if p + ".skip_connection.weight" in sd:
+        x = F.conv2d(x, sd[p + ".skip_connection.weight"], sd[p + ".skip_connection.bias"])
+    h = x + h
+    bf, c, hh, ww = h.shape
+    h5 = h.reshape(batch, bf // batch, c, hh, ww).permute(0, 2, 1, 3, 4)
+    h5 = temporal_conv_block(sd, p + ".temopral_conv", h5)
+    return h5.permute(0, 2, 1, 3, 4).reshape(bf, c, hh, ww)
+
+
+def _kind(sd, p):
+    if p + ".in_layers.0.weight" in sd:
+        return "res"
+    if p + ".transformer_blocks.0.attn1.to_q.weight" in sd:
+        return "temporal" if sd[p + ".proj_in.weight"].dim() == 3 else "spatial"
+    if p + ".op.weight" in sd:
+        return "down"
+    if p + ".conv.weight" in sd:
+        return "up"
+    return None
+
+
+def unet_forward(sd, x, t, y, dim):
+    """UNetSD_T2VBase.forward / _forward_single, unet/unet_t2v.py:210-348 (use_fps_condition
+    False, y given).  The block structure is recovered from the state_dict keys."""
+    b, c, f, h, w = x.shape
+    emb = F.linear(sinusoidal_embedding(t, dim), sd["time_embed.0.weight"], sd["time_embed.0.bias"])
+    emb = F.linear(F.silu(emb), sd["time_embed.2.weight"], sd["time_embed.2.bias"])
+    emb = emb.repeat_interleave(repeats=f, dim=0)
+    context = y.repeat_interleave(repeats=f, dim=0)
+    x = x.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
+
+    def run(p, x):
+        kind = _kind(sd, p)
+        if kind == "res":
+            return resblock(sd, p, x, emb, b)
+        if kind == "spatial":
+            return spatial_transformer(sd, p, x, context)
+        if kind == "temporal":
+            bf, cc, hh, ww = x.shape
+            x5 = x.reshape(b, bf // b, cc, hh, ww).permute(0, 2, 1, 3, 4)
+            x5 = temporal_transformer(sd, p, x5)
+            return x5.permute(0, 2, 1, 3, 4).reshape(bf, cc, hh, ww)
+        if kind == "down":
+            return F.conv2d(x, sd[p + ".op.weight"], sd[p + ".op.bias"], stride=2, padding=1)
+        if kind == "up":
+            x = F.interpolate(x, scale_factor=2, mode="nearest")
+            return F.conv2d(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"], padding=1)
+        raise KeyError(p)
+
+    def run_list(p, x):
+        if _kind(sd, p) is not None:
+            return run(p, x)
+        j = 0
+        while _kind(sd, f"{p}.{j}") is not None:
+            x = run(f"{p}.{j}", x)
+            j += 1
+        return x
+
+    xs = []
+    x = F.conv2d(x, sd["input_blocks.0.0.weight"], sd["input_blocks.0.0.bias"], padding=1)
+    x = run("input_blocks.0.1", x)
+    xs.append(x)
+    i = 1
+    while any(k.startswith(f"input_blocks.{i}.") for k in sd):
+        x = run_list(f"input_blocks.{i}", x)
+        xs.append(x)
+        i += 1
+    x = run_list("middle_block", x)
+    i = 0
+    while any(k.startswith(f"output_blocks.{i}.") for k in sd):
+        x = torch.cat([x, xs.pop()], dim=1)
+        x = run_list(f"output_blocks.{i}", x)
+        i += 1
+    x = F.conv2d(F.silu(_gn(sd, "out.0", x, 1e-5)), sd["out.2.weight"], sd["out.2.bias"], padding=1)
+    return x.reshape(b, f, -1, h, w).permute(0, 2, 1, 3, 4)
+
+
+# ------------------------------------------------------------------------------------------
+# AutoencoderKL
+# ------------------------------------------------------------------------------------------
+
+
+def _swish(x):
+    return x * torch.sigmoid(x)      # autoencoder.py:11-13
+
+
+def vae_resnet(sd, p, x):
+    # ResnetBlock.forward (temb None), autoencoder.py:315-335
+    h = F.conv2d(_swish(_gn(sd, p + ".norm1", x, 1e-6)), sd[p + ".conv1.weight"], sd[p + ".conv1.bias"], padding=1)
+    h = F.conv2d(_swish(_gn(sd, p + ".norm2", h, 1e-6)), sd[p + ".conv2.weight"], sd[p + ".conv2.bias"], padding=1)
+    if p + ".nin_shortcut.weight" in sd:
+        x = F.conv2d(x, sd[p + ".nin_shortcut.weight"], sd[p + ".nin_shortcut.bias"])
+    return x + h
+
+
+def vae_attn(sd, p, x):
+    # AttnBlock.forward, autoencoder.py:418-442
+    h = _gn(sd, p + ".norm", x, 1e-6)
+    q = F.conv2d(h, sd[p + ".q.weight"], sd[p + ".q.bias"])
+    k = F.conv2d(h, sd[p + ".k.weight"], sd[p + ".k.bias"])
+    v = F.conv2d(h, sd[p + ".v.weight"], sd[p + ".v.bias"])
+    b, c, hh, ww = q.shape
+    q = q.reshape(b, c, hh * ww).permute(0, 2, 1)
+    k = k.reshape(b, c, hh * ww)
+    w_ = torch.softmax(torch.bmm(q, k) * (int(c) ** (-0.5)), dim=2)
+    v = v.reshape(b, c, hh * ww)
+    h = torch.bmm(v, w_.permute(0, 2, 1)).reshape(b, c, hh, ww)
+    return x + F.conv2d(h, sd[p + ".proj_out.weight"], sd[p + ".proj_out.bias"])
+
+
+def _vae_mid(sd, p, h):
+    h = vae_resnet(sd, p + ".mid.block_1", h)
+    h = vae_attn(sd, p + ".mid.attn_1", h)
+    return vae_resnet(sd, p + ".mid.block_2", h)
+
+
+def vae_decode(sd, z):
+    # AutoencoderKL.decode -> Decoder.forward, autoencoder.py:100-103, 653-686
+    z = F.conv2d(z, sd["post_quant_conv.weight"], sd["post_quant_conv.bias"])
+    h = F.conv2d(z, sd["decoder.conv_in.weight"], sd["decoder.conv_in.bias"], padding=1)
+    h = _vae_mid(sd, "decoder", h)
+    nlev = 0
+    while f"decoder.up.{nlev}.block.0.norm1.weight" in sd:
+        nlev += 1
+    for lvl in reversed(range(nlev)):
+        j = 0
+        while f"decoder.up.{lvl}.block.{j}.norm1.weight" in sd:
+            h = vae_resnet(sd, f"decoder.up.{lvl}.block.{j}", h)
+            j += 1
+        if lvl != 0:
+            h = F.interpolate(h, scale_factor=2.0, mode="nearest")
+            h = F.conv2d(h, sd[f"decoder.up.{lvl}.upsample.conv.weight"],
+                         sd[f"decoder.up.{lvl}.upsample.conv.bias"], padding=1)
+    h = _swish(_gn(sd, "decoder.norm_out", h, 1e-6))
+    return F.conv2d(h, sd["decoder.conv_out.weight"], sd["decoder.conv_out.bias"], padding=1)
+
+
+def vae_encode_moments(sd, x):
+    # AutoencoderKL.encode -> Encoder.forward + quant_conv, autoencoder.py:79-83, 549-578
+    h = F.conv2d(x, sd["encoder.conv_in.weight"], sd["encoder.conv_in.bias"], padding=1)
+    nlev = 0
+    while f"encoder.down.{nlev}.block.0.norm1.weight" in sd:
+        nlev += 1
+    for lvl in range(nlev):
+        j = 0
+        while f"encoder.down.{lvl}.block.{j}.norm1.weight" in sd:
+            h = vae_resnet(sd, f"encoder.down.{lvl}.block.{j}", h)
+            j += 1
+        if lvl != nlev - 1:
+            h = F.pad(h, (0, 1, 0, 1), mode="constant", value=0)     # autoencoder.py:476-478
+            h = F.conv2d(h, sd[f"encoder.down.{lvl}.downsample.conv.weight"],
+                         sd[f"encoder.down.{lvl}.downsample.conv.bias"], stride=2)
+    h = _vae_mid(sd, "encoder", h)
+    h = _swish(_gn(sd, "encoder.norm_out", h, 1e-6))
+    h = F.conv2d(h, sd["encoder.conv_out.weight"], sd["encoder.conv_out.bias"], padding=1)
+    return F.conv2d(h, sd["quant_conv.weight"], sd["quant_conv.bias"])
+
+
+def gaussian_sample(moments, noise, scale):
+    # DiagonalGaussianDistribution + get_first_stage_encoding, autoencoder.py:212-225, 19-27
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    logvar = torch.clamp(logvar, -30.0, 20.0)
+    return scale * (mean + torch.exp(0.5 * logvar) * noise)
+
+
+# ------------------------------------------------------------------------------------------
+# DDIM sampler (fp32 algebra with fp64 tables cast per use, like `_i`)
+# ------------------------------------------------------------------------------------------
+
+
+def ddim_tables(betas64):
+    # DiffusionDDIM.__init__, diffusions/diffusion_ddim.py:54-70
+    ac = torch.cumprod(1 - betas64, dim=0)
+    return dict(ac=ac, sqrt_ac=torch.sqrt(ac), sqrt_1m=torch.sqrt(1.0 - ac),
+                sqrt_recip=torch.sqrt(1.0 / ac), sqrt_recipm1=torch.sqrt(1.0 / ac - 1))
+
+
+def _i(tab, t, x):
+    # diffusion_ddim.py:10-16
+    return tab[t].view((x.size(0),) + (1,) * (x.ndim - 1)).to(x)
+
+
+def ddim_step(tabs, xt, t, y_out, u_out, guide_scale, mean_type, stride, eta=0.0, noise=None,
+              num_timesteps=1000):
+    """p_mean_variance (CFG + x0) and ddim_sample, diffusion_ddim.py:157-162, 187-197, 230-240."""
+    out = y_out if guide_scale is None else u_out + guide_scale * (y_out - u_out)
+    if mean_type == "v":
+        x0 = _i(tabs["sqrt_ac"], t, xt) * xt - _i(tabs["sqrt_1m"], t, xt) * out
+    elif mean_type == "eps":
+        x0 = _i(tabs["sqrt_recip"], t, xt) * xt - _i(tabs["sqrt_recipm1"], t, xt) * out
+    else:
+        x0 = out
+    eps = (_i(tabs["sqrt_recip"], t, xt) * xt - x0) / _i(tabs["sqrt_recipm1"], t, xt)
+    alphas = _i(tabs["ac"], t, xt)
+    alphas_prev = _i(tabs["ac"], (t - stride).clamp(0), xt)
+    sigmas = eta * torch.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
+    if noise is None:
+        noise = torch.zeros_like(xt)
+    direction = torch.sqrt(1 - alphas_prev - sigmas ** 2) * eps
+    mask = t.ne(0).float().view(-1, *((1,) * (xt.ndim - 1)))
+    xt_1 = torch.sqrt(alphas_prev) * x0 + direction + mask * sigmas * noise
+    return xt_1, x0
+
+
+def ddim_timesteps(num_timesteps, ddim_steps):
+    # diffusion_ddim.py:250
+    return (1 + torch.arange(0, num_timesteps, num_timesteps // ddim_steps)).clamp(0, num_timesteps - 1).flip(0)
+
+
+def ddim_sample_loop(betas64, noise, model, model_kwargs, guide_scale, ddim_steps, mean_type="v", eta=0.0):
+    # DiffusionDDIM.ddim_sample_loop, diffusion_ddim.py:243-254 (two sequential model calls per step)
+    tabs = ddim_tables(betas64)
+    T = len(betas64)
+    xt = noise
+    for step in ddim_timesteps(T, ddim_steps):
+        t = torch.full((noise.size(0),), int(step), dtype=torch.long)
+        y_out = model(xt, t, **model_kwargs[0])
+        u_out = model(xt, t, **model_kwargs[1])
+        xt, _ = ddim_step(tabs, xt, t, y_out, u_out, guide_scale, mean_type, T // ddim_steps, eta,
+                          torch.randn_like(xt) if eta else None, T)
+    return xt

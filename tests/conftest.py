@@ -1,0 +1,55 @@
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (runs through libvgen_hip.so)")
+    config.addinivalue_line("markers", "reference: needs the read-only reference tree (/root/reference)")
+
+
+def pytest_collection_modifyitems(config, items):
+    from oracle import ref_import
+    have_ref = ref_import.available()
+    have_gpu = torch.cuda.is_available()
+    for it in items:
+        if "reference" in it.keywords and not have_ref:
+            it.add_marker(pytest.mark.skip(reason="reference tree not present on this box"))
+        if "gpu" in it.keywords and not have_gpu:
+            it.add_marker(pytest.mark.skip(reason="no GPU"))
+
+
+def gold(name):
+    return torch.load(os.path.join(GOLD, name), map_location="cpu", weights_only=False)
+
+
+@pytest.fixture
+def emu_backend():
+    """Installs the CPU emulator of the C ABI for host-logic tests (test double, never product)."""
+    from oracle.abi_emulator import EmuBackend
+    from vgen_amd import ops
+    prev = ops.set_backend(EmuBackend())
+    yield
+    ops.set_backend(prev)
+
+
+@pytest.fixture
+def hip_backend():
+    from vgen_amd import ops
+    prev = ops.set_backend(None)          # force the real HipBackend
+    be = ops.backend()
+    assert be.name == "hip"
+    yield be
+    ops.set_backend(prev)
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))

@@ -1,0 +1,298 @@
+"""Kernel-level parity cases: every C-ABI op on the GPU (HipBackend) against the CPU emulator of
+the ABI (oracle/abi_emulator.py) on identical seeded inputs.  Shared by tests/test_gpu_kernels.py
+and tests/gpu_diag.py (which dumps per-tile error maps for debugging)."""
+from __future__ import annotations
+
+import torch
+
+from oracle.abi_emulator import EmuBackend
+from vgen_amd import lib as L
+from vgen_amd.ops import Attn, TapGemm
+
+EMU = EmuBackend()
+DTS = {"bf16": torch.bfloat16, "fp16": torch.float16}
+# rel-L2 tolerance of a 16-bit-output kernel vs the fp32-accumulating emulator (one rounding of the
+# output + different summation order); fp32-output kernels are held to 2e-5.
+TOL16 = {"bf16": 4e-3, "fp16": 6e-4}
+TOL32 = 2e-5
+
+
+def _g(seed):
+    return torch.Generator("cpu").manual_seed(seed)
+
+
+def _to_dev(obj, dev):
+    if isinstance(obj, torch.Tensor):
+        return obj.to(dev)
+    return obj
+
+
+def _clone_spec(g, dev):
+    """Deep-copy a TapGemm/Attn spec to a device, preserving views' (offset, strides)."""
+    kw = {}
+    for k, v in g.__dict__.items():
+        if isinstance(v, torch.Tensor):
+            base = v._base if v._base is not None else v
+            nb = base.to(dev)
+            if v._base is not None:
+                nb = torch.as_strided(nb, v.shape, v.stride(), v.storage_offset())
+            kw[k] = nb
+        else:
+            kw[k] = v
+    return type(g)(**kw)
+
+
+def stats(out, ref):
+    out, ref = out.float().cpu(), ref.float().cpu()
+    d = out - ref
+    return dict(rel_l2=float(d.norm() / ref.norm().clamp_min(1e-30)), max_abs=float(d.abs().max()),
+                ref_absmax=float(ref.abs().max()), finite=bool(torch.isfinite(out).all()))
+
+
+# ---------------------------------------------------------------------------------------------
+def case_groupnorm(be, dev, dt, nb, S, C1, C2, silu, raw, eps=1e-5, seed=0):
+    g = _g(seed)
+    x1 = torch.randn(nb * S, C1, generator=g) * 1.7 + 0.6
+    x2 = torch.randn(nb * S, C2, generator=g) * 0.5 - 1.0 if C2 else None
+    C = C1 + C2
+    gamma = 1 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.3 * torch.randn(C, generator=g)
+    y_ref, r_ref = EMU.groupnorm(x1, x2, nb, S, 32, eps, gamma, beta, silu, raw, dt)
+    y, r = be.groupnorm(x1.to(dev), _to_dev(x2, dev), nb, S, 32, eps, gamma.to(dev), beta.to(dev), silu, raw, dt)
+    res = {"y": stats(y, y_ref)}
+    if raw:
+        res["raw"] = stats(r, r_ref)
+    return res
+
+
+def case_layernorm(be, dev, dt, M, d, seed=0):
+    g = _g(seed)
+    x = torch.randn(M, d, generator=g) * 2 + 0.5
+    gamma = 1 + 0.2 * torch.randn(d, generator=g)
+    beta = 0.3 * torch.randn(d, generator=g)
+    ref = EMU.layernorm(x, gamma, beta, 1e-5, dt)
+    y = be.layernorm(x.to(dev), gamma.to(dev), beta.to(dev), 1e-5, dt)
+    return {"y": stats(y, ref)}
+
+
+def make_tapgemm(dt, M, N, C1, mode=L.TAP_LINEAR, C2=0, bias=True, rowbias=0, residual=False,
+                 out_dtype=torch.float32, epilogue=L.EPI_NONE, a_pad=0, w_pad=0, seed=0, **geom):
+    """Build a TapGemm spec on CPU.  a_pad: extra columns in A's storage (lda > C1) to exercise
+    views; w_pad likewise for W (ldw > K)."""
+    g = _g(seed)
+    taps = {L.TAP_LINEAR: 1, L.TAP_CONV3X3: 9, L.TAP_TEMPORAL3: 3}[mode]
+    if mode == L.TAP_CONV3X3:
+        nimg = geom.pop("nimg")
+        src_rows = nimg * geom["Hi"] * geom["Wi"]
+        assert M == nimg * geom["Ho"] * geom["Wo"]
+    else:
+        src_rows = M
+    A = (torch.randn(src_rows, C1 + a_pad, generator=g)).to(dt)[:, :C1]
+    K = taps * C1 + C2
+    W = (torch.randn(N, K + w_pad, generator=g) / (K ** 0.5)).to(dt)[:, :K]
+    spec = dict(A=A, W=W, M=M, N=N, C1=C1, mode=mode, taps=taps, out_dtype=out_dtype, epilogue=epilogue)
+    spec.update(geom)
+    if C2:
+        spec.update(A2=torch.randn(M, C2, generator=g).to(dt), C2=C2)
+    if bias:
+        spec["bias"] = torch.randn(N, generator=g)
+    if rowbias:
+        nbat = (M + rowbias - 1) // rowbias
+        spec.update(rowbias=torch.randn(nbat, N + 8, generator=g)[:, 4:4 + N], rows_per_rb=rowbias)
+    n_out = N // 2 if epilogue == L.EPI_GEGLU else N
+    if residual:
+        spec["residual"] = torch.randn(M, n_out, generator=g)
+    return TapGemm(**spec)
+
+
+def case_tapgemm(be, dev, spec, want_map=False):
+    ref = EMU.tapgemm(spec)
+    out = be.tapgemm(_clone_spec(spec, dev))
+    res = {"out": stats(out, ref)}
+    if want_map:
+        d = (out.float().cpu() - ref.float()).abs()
+        M, N = d.shape
+        # coarse error map over (64-row, 16-col) tiles to localise layout bugs
+        tm, tn = (M + 63) // 64, (N + 15) // 16
+        emap = torch.zeros(tm, tn)
+        for i in range(tm):
+            for j in range(tn):
+                emap[i, j] = d[i * 64:(i + 1) * 64, j * 16:(j + 1) * 16].max()
+        res["emap"] = emap.tolist()
+        res["sample_out"] = out.float().cpu()[:4, :8].tolist()
+        res["sample_ref"] = ref.float()[:4, :8].tolist()
+    return res
+
+
+def make_attn(dt, kind, seed=0, **p):
+    g = _g(seed)
+    heads = p["heads"]
+    d = heads * 64
+    if kind == "spatial":        # packed qkv [nb*N, 3d]
+        nb, N = p["nb"], p["N"]
+        qkv = (torch.randn(nb * N, 3 * d, generator=g) * p.get("amp", 1.0)).to(dt)
+        out = torch.zeros(nb * N, d, dtype=dt)
+        ld = 3 * d
+        return Attn(q=qkv, k=qkv[:, d:], v=qkv[:, 2 * d:], out=out, heads=heads, nq=N, nk=N, nbatch=nb,
+                    inner=1, q_s=(ld, N * ld, 0), k_s=(ld, N * ld, 0), v_s=(ld, N * ld, 0),
+                    o_s=(d, N * d, 0), scale=0.125)
+    if kind == "cross":          # q [B*F*N, d]; kv [B*Lc, kw] slices
+        B, F, N, Lc, off, kw = p["B"], p["F"], p["N"], p["Lc"], p["off"], p["kw"]
+        q = torch.randn(B * F * N, d, generator=g).to(dt)
+        kv = torch.randn(B * Lc, kw, generator=g).to(dt)
+        out = torch.zeros(B * F * N, d, dtype=dt)
+        return Attn(q=q, k=kv[:, off:off + d], v=kv[:, off + d: off + 2 * d], out=out, heads=heads, nq=N,
+                    nk=Lc, nbatch=B * F, inner=F, q_s=(d, F * N * d, N * d), k_s=(kw, Lc * kw, 0),
+                    v_s=(kw, Lc * kw, 0), o_s=(d, F * N * d, N * d), scale=0.125)
+    if kind == "temporal":       # packed qkv [B*F*S, 3d], sequences over frames
+        B, F, S = p["B"], p["F"], p["S"]
+        qkv = (torch.randn(B * F * S, 3 * d, generator=g) * p.get("amp", 1.0)).to(dt)
+        out = torch.zeros(B * F * S, d, dtype=dt)
+        ld = 3 * d
+        s3 = (S * ld, F * S * ld, ld)
+        return Attn(q=qkv, k=qkv[:, d:], v=qkv[:, 2 * d:], out=out, heads=heads, nq=F, nk=F, nbatch=B * S,
+                    inner=S, q_s=s3, k_s=s3, v_s=s3, o_s=(S * d, F * S * d, d), scale=0.125)
+    raise ValueError(kind)
+
+
+def case_attention(be, dev, spec):
+    ref = EMU.attention(_clone_spec(spec, "cpu")).clone()
+    out = be.attention(_clone_spec(spec, dev))
+    return {"out": stats(out, ref)}
+
+
+def case_softmax_rows(be, dev, dt, rows, cols, ldp, seed=0):
+    g = _g(seed)
+    S = torch.randn(rows, cols + 3, generator=g)[:, :cols] * 4
+    ref = EMU.softmax_rows(S, cols, 0.37, dt)
+    P = torch.zeros(rows, ldp, dtype=dt, device=dev)
+    Sd = torch.as_strided(S._base.to(dev), S.shape, S.stride(), S.storage_offset())
+    be.softmax_rows(Sd, cols, 0.37, dt, out=P)
+    pad_ok = bool((P[:, cols:] == 0).all())
+    r = stats(P[:, :cols], ref)
+    r["pad_untouched"] = pad_ok
+    return {"P": r}
+
+
+def case_act_cast(be, dev, dt, n, act, seed=0):
+    x = torch.randn(n, generator=_g(seed)) * 3
+    return {"y": stats(be.act_cast(x.to(dev), act, dt), EMU.act_cast(x, act, dt))}
+
+
+def case_timestep_embedding(be, dev, dt, dim):
+    t = torch.tensor([981.0, 1.0, 400.0, 0.0])
+    return {"y": stats(be.timestep_embedding(t.to(dev), dim, dt), EMU.timestep_embedding(t, dim, dt))}
+
+
+def case_im2col(be, dev, dt, layout, seed=0):
+    g = _g(seed)
+    if layout == "bcfhw":
+        B, C, F, H, W = 2, 4, 3, 6, 5
+        src = torch.randn(B, C, F, H, W, generator=g)
+        s = (C * F * H * W, H * W, F * H * W, W, 1)
+        nimg, Fi = B * F, F
+    else:                        # rows [n*H*W, C]
+        n, C, H, W = 3, 3, 5, 7
+        src = torch.randn(n * H * W, C, generator=g)
+        s = (H * W * C, 0, 1, W * C, C)
+        nimg, Fi = n, 1
+    ref = EMU.im2col3x3_small(src, nimg, Fi, C, H, W, s, 64, dt)
+    out = be.im2col3x3_small(src.to(dev), nimg, Fi, C, H, W, s, 64, dt)
+    return {"col": stats(out, ref)}
+
+
+def case_pointwise(be, dev, seed=0):
+    g = _g(seed)
+    n, C, H, W, Co = 2, 4, 5, 6, 3
+    src = torch.randn(n, C, H, W, generator=g)
+    Wm = torch.randn(Co, C, generator=g)
+    b = torch.randn(Co, generator=g)
+    s = (C * H * W, 0, H * W, W, 1)
+    d = (H * W * Co, 0, 1, W * Co, Co)
+    ref = EMU.pointwise_small(src, n, 1, C, H, W, s, Wm, b, Co, torch.zeros(n * H * W, Co), d)
+    out = be.pointwise_small(src.to(dev), n, 1, C, H, W, s, Wm.to(dev), b.to(dev), Co,
+                             torch.zeros(n * H * W, Co, device=dev), d)
+    return {"out": stats(out, ref)}
+
+
+def case_cfg_ddim(be, dev, mean_type, eta, seed=0):
+    g = _g(seed)
+    B = 2
+    shp = (B, 4, 3, 8, 8)
+    xt, y, u = (torch.randn(shp, generator=g) for _ in range(3))
+    noise = torch.randn(shp, generator=g) if eta else None
+    ac = torch.tensor([0.3, 0.9])
+    acp = torch.tensor([0.5, 0.97])
+    sig = eta * torch.sqrt((1 - acp) / (1 - ac) * (1 - ac / acp))
+    coef = torch.stack([ac.sqrt(), (1 - ac).sqrt(), (1 / ac).sqrt(), (1 / ac - 1).sqrt(), acp, sig,
+                        torch.tensor([1.0, 0.0])], 1).contiguous()
+    r_ref, x0_ref = EMU.cfg_ddim_step(xt, y, u, noise, coef, 9.0, True, mean_type, True)
+    r, x0 = be.cfg_ddim_step(xt.to(dev), y.to(dev), u.to(dev), _to_dev(noise, dev), coef.to(dev), 9.0, True,
+                             mean_type, True)
+    res = {"xt_1": stats(r, r_ref), "x0": stats(x0, x0_ref)}
+    res["xt_1"]["bit_exact"] = bool(torch.equal(r.cpu(), r_ref))
+    res["x0"]["bit_exact"] = bool(torch.equal(x0.cpu(), x0_ref))
+    return res
+
+
+def case_gaussian(be, dev, seed=0):
+    g = _g(seed)
+    n, zc, H, W = 2, 4, 5, 6
+    mom = torch.randn(n * H * W, 2 * zc, generator=g) * 3
+    noise = torch.randn(n, zc, H, W, generator=g)
+    ref = EMU.gaussian_sample(mom, noise, n, zc, H * W, 0.18215)
+    out = be.gaussian_sample(mom.to(dev), noise.to(dev), n, zc, H * W, 0.18215)
+    return {"z": stats(out, ref)}
+
+
+# --- the case table -----------------------------------------------------------------------------
+GN_CASES = [  # nb, S, C1, C2, silu, raw
+    (16, 128, 320, 0, True, False), (2, 96, 1280, 640, True, True), (1, 256, 64, 0, False, False),
+    (3, 50, 128, 0, True, False), (1, 37, 2560, 0, True, False), (2, 1792, 320, 0, True, False),
+    (2, 33, 640, 320, True, True),
+]
+LN_CASES = [(100, 320), (7, 1280), (300, 64), (5, 512), (1, 2048)]
+
+
+def tapgemm_cases(dt):
+    c = {}
+    c["lin_300x320x320_b64"] = make_tapgemm(dt, 300, 320, 320)
+    c["lin_1000x256x640_b128"] = make_tapgemm(dt, 1000, 256, 640, residual=True)
+    c["lin_77x128x1024_out16"] = make_tapgemm(dt, 77, 128, 1024, out_dtype=dt, bias=False)
+    c["lin_500x4x576_smallN"] = make_tapgemm(dt, 500, 4, 576)
+    c["lin_130x3x128_nonvec"] = make_tapgemm(dt, 130, 3, 128, residual=True)
+    c["lin_2x1280x320_tinyM"] = make_tapgemm(dt, 2, 1280, 320)
+    c["lin_views_lda_ldw"] = make_tapgemm(dt, 200, 192, 128, a_pad=64, w_pad=128, residual=True)
+    c["lin_rowbias"] = make_tapgemm(dt, 384, 128, 64, rowbias=96, residual=True)
+    c["lin_geglu"] = make_tapgemm(dt, 200, 512, 64, epilogue=L.EPI_GEGLU, out_dtype=dt)
+    c["lin_geglu_b64"] = make_tapgemm(dt, 150, 320, 128, epilogue=L.EPI_GEGLU, out_dtype=dt, residual=True)
+    c["conv_s1"] = make_tapgemm(dt, 3 * 9 * 7, 128, 64, mode=L.TAP_CONV3X3, nimg=3, Hi=9, Wi=7, Ho=9, Wo=7,
+                                stride=1, pad_t=1, pad_l=1, ups=0, rowbias=63)
+    c["conv_s2_pad1"] = make_tapgemm(dt, 2 * 5 * 4, 64, 128, mode=L.TAP_CONV3X3, nimg=2, Hi=10, Wi=8, Ho=5,
+                                     Wo=4, stride=2, pad_t=1, pad_l=1, ups=0)
+    c["conv_s2_odd"] = make_tapgemm(dt, 2 * 4 * 4, 64, 64, mode=L.TAP_CONV3X3, nimg=2, Hi=7, Wi=7, Ho=4,
+                                    Wo=4, stride=2, pad_t=1, pad_l=1, ups=0)
+    c["conv_ups"] = make_tapgemm(dt, 2 * 10 * 12, 192, 64, mode=L.TAP_CONV3X3, nimg=2, Hi=5, Wi=6, Ho=10,
+                                 Wo=12, stride=1, pad_t=1, pad_l=1, ups=1)
+    c["conv_vae_down"] = make_tapgemm(dt, 2 * 4 * 3, 64, 64, mode=L.TAP_CONV3X3, nimg=2, Hi=8, Wi=6, Ho=4,
+                                      Wo=3, stride=2, pad_t=0, pad_l=0, ups=0)
+    c["conv_skipseg"] = make_tapgemm(dt, 2 * 6 * 6, 128, 128, mode=L.TAP_CONV3X3, nimg=2, Hi=6, Wi=6, Ho=6,
+                                     Wo=6, stride=1, pad_t=1, pad_l=1, ups=0, C2=192)
+    c["conv_big"] = make_tapgemm(dt, 4 * 32 * 56, 320, 320, mode=L.TAP_CONV3X3, nimg=4, Hi=32, Wi=56,
+                                 Ho=32, Wo=56, stride=1, pad_t=1, pad_l=1, ups=0, residual=True)
+    c["temporal"] = make_tapgemm(dt, 2 * 5 * 24, 64, 64, mode=L.TAP_TEMPORAL3, F=5, S=24, residual=True)
+    c["temporal_b128"] = make_tapgemm(dt, 1 * 16 * 28, 128, 128, mode=L.TAP_TEMPORAL3, F=16, S=28)
+    return c
+
+
+def attn_cases(dt):
+    c = {}
+    c["spatial_200"] = make_attn(dt, "spatial", heads=2, nb=3, N=200)
+    c["spatial_28"] = make_attn(dt, "spatial", heads=3, nb=2, N=28)
+    c["spatial_448_peaky"] = make_attn(dt, "spatial", heads=1, nb=1, N=448, amp=3.0)
+    c["cross_77"] = make_attn(dt, "cross", heads=2, B=2, F=3, N=130, Lc=77, off=256, kw=640)
+    c["cross_1"] = make_attn(dt, "cross", heads=1, B=1, F=2, N=40, Lc=1, off=0, kw=128)
+    c["temporal_16"] = make_attn(dt, "temporal", heads=2, B=2, F=16, S=30)
+    c["temporal_4"] = make_attn(dt, "temporal", heads=1, B=1, F=4, S=9, amp=2.0)
+    c["temporal_32_flash"] = make_attn(dt, "temporal", heads=1, B=1, F=32, S=6)
+    return c

@@ -1,0 +1,79 @@
+"""C-ABI boundary: the library builds/loads and exports exactly what include/vgen_hip.h declares;
+the product path fails loudly (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import ROOT
+from vgen_amd import lib, ops
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "vgen_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return set(re.findall(r"\b(vgen_[a-z0-9_]+)\s*\(", src))
+
+
+def test_header_and_binding_agree():
+    assert _header_symbols() == set(lib.SYMBOLS)
+
+
+def test_library_loads_and_exports_every_symbol():
+    import __graft_entry__
+    __graft_entry__.build()
+    l = lib.load()
+    for name in _header_symbols():
+        assert hasattr(l, name), name
+    assert l.vgen_version() == lib.ABI_VERSION
+    assert isinstance(l.vgen_last_error(), bytes)
+
+
+def test_struct_layout_matches_header():
+    # field order/count of the ctypes mirrors vs the header text
+    src = open(os.path.join(ROOT, "include", "vgen_hip.h")).read()
+    body = re.search(r"typedef struct vgen_tapgemm_args \{(.*?)\} vgen_tapgemm_args;", src, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        decl = re.sub(r"^(const\s+)?(void|float|int32_t|int64_t)\s*\*?", "", decl)
+        names += [n.strip(" *") for n in decl.split(",")]
+    assert names == [f[0] for f in lib.TapGemmArgs._fields_]
+    body = re.search(r"typedef struct vgen_attn_args \{(.*?)\} vgen_attn_args;", src, re.S).group(1)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        decl = re.sub(r"^(const\s+)?(void|float|int32_t|int64_t)\s*\*?", "", decl)
+        names += [n.strip(" *") for n in decl.split(",")]
+    assert names == [f[0] for f in lib.AttnArgs._fields_]
+
+
+def test_missing_library_fails_loudly(tmp_path):
+    with pytest.raises(lib.VgenHipError):
+        lib.load(str(tmp_path / "nope.so"))
+
+
+def test_cpu_tensor_is_rejected_not_emulated():
+    prev = ops.set_backend(None)
+    try:
+        be = ops.backend()
+        x = torch.zeros(8, 64)
+        with pytest.raises(lib.VgenHipError):
+            be.layernorm(x, torch.ones(64), torch.zeros(64), 1e-5, torch.bfloat16)
+    finally:
+        ops.set_backend(prev)
+
+
+def test_badarg_reported_without_gpu():
+    l = lib.load()
+    a = lib.TapGemmArgs()
+    a.M, a.N, a.dtype, a.C1, a.taps = 16, 16, lib.VGEN_BF16, 60, 1   # C1 not a multiple of 64
+    rc = l.vgen_tapgemm(ctypes.byref(a), None)
+    assert rc == -1 and b"C1" in l.vgen_last_error()

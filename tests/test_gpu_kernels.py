@@ -1,0 +1,82 @@
+"""-m gpu: every C-ABI kernel on the MI355X vs the CPU emulator of the ABI (identical seeded
+inputs).  Tolerances: 16-bit outputs TOL16[dtype] rel-L2 (one output rounding + summation
+order), fp32 outputs 2e-5; the fused CFG+DDIM update must be BIT-EXACT."""
+import pytest
+import torch
+
+import kernel_cases as kc
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _check(res, dtname, out_is_16=None):
+    for name, st in res.items():
+        assert st["finite"], (name, st)
+        tol = kc.TOL16[dtname] if (out_is_16 is None or out_is_16) else kc.TOL32
+        assert st["rel_l2"] <= tol, (name, st, tol)
+
+
+@pytest.mark.parametrize("dtname", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", kc.GN_CASES, ids=lambda c: "nb%d_S%d_C%d+%d" % c[:4])
+def test_groupnorm(hip_backend, dtname, case):
+    _check(kc.case_groupnorm(hip_backend, DEV, kc.DTS[dtname], *case), dtname)
+
+
+@pytest.mark.parametrize("dtname", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", kc.LN_CASES, ids=lambda c: "M%d_d%d" % c)
+def test_layernorm(hip_backend, dtname, case):
+    _check(kc.case_layernorm(hip_backend, DEV, kc.DTS[dtname], *case), dtname)
+
+
+_TG = sorted(kc.tapgemm_cases(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtname", ["bf16", "fp16"])
+@pytest.mark.parametrize("name", _TG)
+def test_tapgemm(hip_backend, dtname, name):
+    spec = kc.tapgemm_cases(kc.DTS[dtname])[name]
+    res = kc.case_tapgemm(hip_backend, DEV, spec)
+    _check(res, dtname, out_is_16=spec.out_dtype != torch.float32)
+
+
+_AT = sorted(kc.attn_cases(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtname", ["bf16", "fp16"])
+@pytest.mark.parametrize("name", _AT)
+def test_attention(hip_backend, dtname, name):
+    spec = kc.attn_cases(kc.DTS[dtname])[name]
+    res = kc.case_attention(hip_backend, DEV, spec)
+    # P is rounded to 16 bit before the PV product (like every flash kernel): 3x the plain bound
+    for st in res.values():
+        assert st["finite"] and st["rel_l2"] <= 3 * kc.TOL16[dtname], st
+
+
+@pytest.mark.parametrize("dtname", ["bf16", "fp16"])
+def test_softmax_rows(hip_backend, dtname):
+    res = kc.case_softmax_rows(hip_backend, DEV, kc.DTS[dtname], 70, 200, 256)
+    assert res["P"]["pad_untouched"]
+    _check(res, dtname)
+
+
+@pytest.mark.parametrize("dtname", ["bf16", "fp16"])
+def test_small_kernels(hip_backend, dtname):
+    dt = kc.DTS[dtname]
+    _check(kc.case_act_cast(hip_backend, DEV, dt, 5000, 1), dtname)
+    _check(kc.case_act_cast(hip_backend, DEV, dt, 777, 0), dtname)
+    _check(kc.case_timestep_embedding(hip_backend, DEV, dt, 320), dtname)
+    _check(kc.case_im2col(hip_backend, DEV, dt, "bcfhw"), dtname)
+    _check(kc.case_im2col(hip_backend, DEV, dt, "rows"), dtname)
+
+
+def test_pointwise_and_gaussian(hip_backend):
+    _check(kc.case_pointwise(hip_backend, DEV), "fp16", out_is_16=False)
+    _check(kc.case_gaussian(hip_backend, DEV), "fp16", out_is_16=False)
+
+
+@pytest.mark.parametrize("mean_type", [0, 1, 2])
+@pytest.mark.parametrize("eta", [0.0, 0.7])
+def test_cfg_ddim_step_bit_exact(hip_backend, mean_type, eta):
+    res = kc.case_cfg_ddim(hip_backend, DEV, mean_type, eta)
+    assert res["xt_1"]["bit_exact"] and res["x0"]["bit_exact"], res

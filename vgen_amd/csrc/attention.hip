@@ -1,0 +1,372 @@
+// attention.hip — fused softmax(Q K^T * scale) V for head_dim 64 on gfx950 MFMA.
+//
+// Two kernels (see include/vgen_hip.h for the strided sequence addressing):
+//
+//  flash_kernel    : general nq x nk (spatial self-attention 1792/448/112/28 tokens, cross
+//                    attention over 77 context tokens).  Block = 4 waves x 32 queries, KV tiles
+//                    of 64 keys staged through LDS, online softmax in fp32.
+//                    Both products are computed TRANSPOSED so that every lane owns exactly one
+//                    query column:
+//                      S^T[key, q]  = mfma(A = K-frag [16 keys x 32 d], B = Q-frag [32 d x 16 q])
+//                      O^T[d, q]   += mfma(A = V^T-frag [16 d x 32 keys], B = P^T-frag)
+//                    -> the softmax max/sum are in-lane over 16 scores plus two xor-shuffles,
+//                       the rescale factor is one scalar per lane, and the C/D layout of S^T
+//                       (4 consecutive keys per lane) IS the B-operand layout of the PV product
+//                       (any k-permutation is legal as long as A and B agree), so P never
+//                       leaves registers.  V is written to LDS transposed ([d][key]) so the
+//                       matching A fragments are two ds_read_b64 each.
+//
+//  temporal_kernel : nq, nk <= 16 (attention over the 16 frames of one pixel; batch = B*H*W,
+//                    up to 8960 sequences x heads).  One wave per (sequence, head): Q/K
+//                    fragments are loaded straight from global in MFMA operand layout, S^T is
+//                    2 MFMA 16x16x32, the softmax is in-lane + 2 shuffles, and P V uses the
+//                    K=16 MFMA (16x16x16) whose B layout again equals S^T's C/D layout.
+#include "common.h"
+
+namespace {
+
+constexpr int HD = 64;  // head dim
+
+__device__ __forceinline__ int64_t seq_off(int64_t bi, int64_t inner, int64_t bo, int64_t bin) {
+  return (bi / inner) * bo + (bi % inner) * bin;
+}
+
+// =========================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void flash_kernel(const vgen_attn_args p, int qtiles) {
+  constexpr int BQ = 128, BKV = 64;
+  constexpr int VS = 72;  // V^T row stride in elements (64 keys + 8 pad) -> 144 B
+  __shared__ __attribute__((aligned(16))) unsigned char sK[BKV * 128];      // [key][64 d] swizzled
+  __shared__ __attribute__((aligned(16))) uint16_t sVt[HD * VS];             // [d][key]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+
+  int64_t bid = blockIdx.x;
+  const int qt = (int)(bid % qtiles);
+  bid /= qtiles;
+  const int h = (int)(bid % p.heads);
+  const int64_t bi = bid / p.heads;
+
+  const uint16_t* Q = (const uint16_t*)p.q + seq_off(bi, p.inner, p.q_bo, p.q_bi) + h * HD;
+  const uint16_t* K = (const uint16_t*)p.k + seq_off(bi, p.inner, p.k_bo, p.k_bi) + h * HD;
+  const uint16_t* V = (const uint16_t*)p.v + seq_off(bi, p.inner, p.v_bo, p.v_bi) + h * HD;
+  uint16_t* O = (uint16_t*)p.out + seq_off(bi, p.inner, p.o_bo, p.o_bi) + h * HD;
+
+  const int q0 = qt * BQ + wave * 32;
+
+  // Q fragments (B operand): lane (lq, lr): Q[q0 + qf*16 + lr][32*ks + 8*lq .. +8]
+  u32x4 qf[2][2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int row = q0 + f * 16 + lr;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (row < p.nq) v = *(const u32x4*)(Q + (int64_t)row * p.q_rs + ks * 32 + lq * 8);
+      qf[f][ks] = v;
+    }
+
+  f32x4 o_acc[2][4];
+  float m_run[2], l_run[2];
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    m_run[f] = -INFINITY;
+    l_run[f] = 0.f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) o_acc[f][d] = f32x4{0, 0, 0, 0};
+  }
+  const float c = p.scale * 1.44269504088896340736f;  // scores -> log2 domain
+
+  // staging assignments
+  const int k_row = tid >> 2, k_ch = (tid & 3) * 2;  // K: row, two 16-B chunks
+  const int v_key = tid & 63, v_d0 = (tid >> 6) * 16;  // V: key, 16 d values (two 16-B chunks)
+
+  for (int kv0 = 0; kv0 < p.nk; kv0 += BKV) {
+    __syncthreads();  // previous tile fully consumed
+    {
+      u32x4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
+      if (kv0 + k_row < p.nk) {
+        const uint16_t* src = K + (int64_t)(kv0 + k_row) * p.k_rs + k_ch * 8;
+        a = *(const u32x4*)src;
+        b = *(const u32x4*)(src + 8);
+      }
+      unsigned char* dst = sK + k_row * 128;
+      *(u32x4*)(dst + (((k_ch) ^ (k_row & 7)) << 4)) = a;
+      *(u32x4*)(dst + (((k_ch + 1) ^ (k_row & 7)) << 4)) = b;
+    }
+    {
+      u32x4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
+      if (kv0 + v_key < p.nk) {
+        const uint16_t* src = V + (int64_t)(kv0 + v_key) * p.v_rs + v_d0;
+        a = *(const u32x4*)src;
+        b = *(const u32x4*)(src + 8);
+      }
+      const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        sVt[(v_d0 + 2 * e) * VS + v_key] = (uint16_t)(w[e] & 0xffffu);
+        sVt[(v_d0 + 2 * e + 1) * VS + v_key] = (uint16_t)(w[e] >> 16);
+      }
+    }
+    __syncthreads();
+
+    // ---- S^T = K Q^T for both query fragments; K fragments shared ------------------------
+    f32x4 s[2][4];
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf) s[f][kf] = f32x4{0, 0, 0, 0};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int co = ((ks * 4 + lq) ^ (lr & 7)) << 4;
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf) {
+        const u32x4 kfrag = *(const u32x4*)(sK + (kf * 16 + lr) * 128 + co);
+        s[0][kf] = T::mfma32(kfrag, qf[0][ks], s[0][kf]);
+        s[1][kf] = T::mfma32(kfrag, qf[1][ks], s[1][kf]);
+      }
+    }
+
+    // ---- online softmax; lane (lq, lr) holds keys kv0 + 16*kf + 4*lq + r of query lr ------
+    u32x4 pb[2][2];
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      float mx = -INFINITY;
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kv0 + kf * 16 + lq * 4 + r;
+          const float v = key < p.nk ? s[f][kf][r] : -INFINITY;
+          s[f][kf][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[f], mx);  // finite: every tile has >= 1 valid key
+      const float alpha = exp2f((m_run[f] - m_new) * c);
+      m_run[f] = m_new;
+      float psum = 0.f;
+      float pv[4][4];
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = exp2f((s[f][kf][r] - m_new) * c);
+          pv[kf][r] = e;
+          psum += e;
+        }
+      l_run[f] = l_run[f] * alpha + psum;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) o_acc[f][d] *= alpha;
+      // B operand of the PV product for key-step st: keys {32st + 4lq + r} U {32st + 16 + 4lq + r}
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        u32x4 t;
+        t.x = pack2<T>(pv[2 * st][0], pv[2 * st][1]);
+        t.y = pack2<T>(pv[2 * st][2], pv[2 * st][3]);
+        t.z = pack2<T>(pv[2 * st + 1][0], pv[2 * st + 1][1]);
+        t.w = pack2<T>(pv[2 * st + 1][2], pv[2 * st + 1][3]);
+        pb[f][st] = t;
+      }
+    }
+
+    // ---- O^T += V^T P^T ------------------------------------------------------------------
+#pragma unroll
+    for (int st = 0; st < 2; ++st)
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const uint16_t* vr = sVt + (d * 16 + lr) * VS + st * 32 + lq * 4;
+        const u32x2 lo = *(const u32x2*)vr;
+        const u32x2 hi = *(const u32x2*)(vr + 16);
+        const u32x4 vfrag = {lo.x, lo.y, hi.x, hi.y};
+        o_acc[0][d] = T::mfma32(vfrag, pb[0][st], o_acc[0][d]);
+        o_acc[1][d] = T::mfma32(vfrag, pb[1][st], o_acc[1][d]);
+      }
+  }
+
+  // ---- normalise and store: lane (lq, lr) owns O[q = lr][d = 16*dd + 4*lq + r] -------------
+#pragma unroll
+  for (int f = 0; f < 2; ++f) {
+    float l = l_run[f];
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    const float inv = 1.0f / l;
+    const int row = q0 + f * 16 + lr;
+    if (row < p.nq) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const f32x4 o = o_acc[f][d] * inv;
+        *(u32x2*)(O + (int64_t)row * p.o_rs + d * 16 + lq * 4) = pack4<T>(o.x, o.y, o.z, o.w);
+      }
+    }
+  }
+}
+
+// =========================================================================================
+template <typename T>
+__global__ __launch_bounds__(256) void temporal_kernel(const vgen_attn_args p, int64_t npairs) {
+  constexpr int VS = 72;
+  __shared__ __attribute__((aligned(16))) uint16_t sV[4][16 * VS];  // per wave: [key][64 d + pad]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, lq = lane >> 4;
+  const int64_t pair = (int64_t)blockIdx.x * 4 + wave;
+  const bool live = pair < npairs;
+  const int64_t pr = live ? pair : 0;
+  const int h = (int)(pr % p.heads);
+  const int64_t bi = pr / p.heads;
+
+  const uint16_t* Q = (const uint16_t*)p.q + seq_off(bi, p.inner, p.q_bo, p.q_bi) + h * HD;
+  const uint16_t* K = (const uint16_t*)p.k + seq_off(bi, p.inner, p.k_bo, p.k_bi) + h * HD;
+  const uint16_t* V = (const uint16_t*)p.v + seq_off(bi, p.inner, p.v_bo, p.v_bi) + h * HD;
+  uint16_t* O = (uint16_t*)p.out + seq_off(bi, p.inner, p.o_bo, p.o_bi) + h * HD;
+
+  // operand fragments straight from global: lane (lq, lr): X[lr][32*ks + 8*lq .. +8]
+  u32x4 qf[2], kf[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    u32x4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
+    if (live && lr < p.nq) a = *(const u32x4*)(Q + (int64_t)lr * p.q_rs + ks * 32 + lq * 8);
+    if (live && lr < p.nk) b = *(const u32x4*)(K + (int64_t)lr * p.k_rs + ks * 32 + lq * 8);
+    qf[ks] = a;
+    kf[ks] = b;
+  }
+  // V tile -> LDS row-major: lane -> key = lane >> 2, chunks 2*(lane&3), +1
+  {
+    const int key = lane >> 2, ch = (lane & 3) * 2;
+    u32x4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
+    if (live && key < p.nk) {
+      const uint16_t* src = V + (int64_t)key * p.v_rs + ch * 8;
+      a = *(const u32x4*)src;
+      b = *(const u32x4*)(src + 8);
+    }
+    uint16_t* dst = &sV[wave][key * VS + ch * 8];
+    *(u32x4*)dst = a;
+    *(u32x4*)(dst + 8) = b;
+  }
+  __syncthreads();
+
+  f32x4 s = {0, 0, 0, 0};
+  s = T::mfma32(kf[0], qf[0], s);
+  s = T::mfma32(kf[1], qf[1], s);  // lane: S^T[key = 4*lq + r][query = lr]
+
+  const float c = p.scale * 1.44269504088896340736f;
+  float mx = -INFINITY;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const float v = (lq * 4 + r) < p.nk ? s[r] : -INFINITY;
+    s[r] = v;
+    mx = fmaxf(mx, v);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  float e[4], sum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    e[r] = exp2f((s[r] - mx) * c);
+    sum += e[r];
+  }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+  const u32x2 pb = pack4<T>(e[0] * inv, e[1] * inv, e[2] * inv, e[3] * inv);
+
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    // A operand: V^T[d*16 + lr][key = 4*lq + r]
+    const uint16_t* vr = &sV[wave][(lq * 4) * VS + d * 16 + lr];
+    u32x2 vfrag;
+    vfrag.x = (uint32_t)vr[0] | ((uint32_t)vr[VS] << 16);
+    vfrag.y = (uint32_t)vr[2 * VS] | ((uint32_t)vr[3 * VS] << 16);
+    f32x4 o = {0, 0, 0, 0};
+    o = T::mfma16(vfrag, pb, o);  // O^T[d*16 + 4*lq + r][query = lr]
+    if (live && lr < p.nq)
+      *(u32x2*)(O + (int64_t)lr * p.o_rs + d * 16 + lq * 4) = pack4<T>(o.x, o.y, o.z, o.w);
+  }
+}
+
+}  // namespace
+
+extern "C" int vgen_attention(const vgen_attn_args* args, void* stream) {
+  if (!args) {
+    vgen_set_error("attention: null args");
+    return VGEN_E_BADARG;
+  }
+  const vgen_attn_args& a = *args;
+  VGEN_REQUIRE(a.dtype == VGEN_BF16 || a.dtype == VGEN_F16, "attention: dtype");
+  VGEN_REQUIRE(a.heads > 0 && a.nq > 0 && a.nk > 0 && a.nbatch > 0 && a.inner > 0,
+               "attention: bad sizes");
+  VGEN_REQUIRE(vgen_aligned16(a.q) && vgen_aligned16(a.k) && vgen_aligned16(a.v) &&
+                   vgen_aligned16(a.out),
+               "attention: pointer alignment");
+  VGEN_REQUIRE((a.q_rs | a.q_bo | a.q_bi | a.k_rs | a.k_bo | a.k_bi | a.v_rs | a.v_bo | a.v_bi |
+                a.o_rs | a.o_bo | a.o_bi) % 8 == 0,
+               "attention: strides must be multiples of 8 elements");
+  hipStream_t s = (hipStream_t)stream;
+  if (a.nq <= 16 && a.nk <= 16) {
+    const int64_t npairs = a.nbatch * a.heads;
+    const int64_t grid = (npairs + 3) / 4;
+    VGEN_REQUIRE(grid < (1LL << 31), "attention: grid too large");
+    if (a.dtype == VGEN_BF16)
+      hipLaunchKernelGGL(temporal_kernel<BF16>, dim3((unsigned)grid), dim3(256), 0, s, a, npairs);
+    else
+      hipLaunchKernelGGL(temporal_kernel<F16>, dim3((unsigned)grid), dim3(256), 0, s, a, npairs);
+    return vgen_check_launch("attention(temporal)");
+  }
+  const int qtiles = (a.nq + 127) / 128;
+  const int64_t grid = a.nbatch * a.heads * qtiles;
+  VGEN_REQUIRE(grid < (1LL << 31), "attention: grid too large");
+  if (a.dtype == VGEN_BF16)
+    hipLaunchKernelGGL(flash_kernel<BF16>, dim3((unsigned)grid), dim3(256), 0, s, a, qtiles);
+  else
+    hipLaunchKernelGGL(flash_kernel<F16>, dim3((unsigned)grid), dim3(256), 0, s, a, qtiles);
+  return vgen_check_launch("attention(flash)");
+}
+
+// =========================================================================================
+// Row softmax for the VAE's single-head 512-channel attention (scores via tap-GEMM).
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S,
+                                                           int cols, int64_t lds, float scale,
+                                                           uint16_t* __restrict__ P, int64_t ldp) {
+  __shared__ float red[4];
+  const int64_t row = blockIdx.x;
+  const float* sr = S + row * lds;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float mx = -INFINITY;
+  for (int c = tid; c < cols; c += 256) mx = fmaxf(mx, sr[c]);
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  __syncthreads();
+  const float cs = scale * 1.44269504088896340736f;
+  float sum = 0.f;
+  for (int c = tid; c < cols; c += 256) sum += exp2f((sr[c] - mx) * cs);
+  sum = wave_sum(sum);
+  if (lane == 0) red[wave] = sum;
+  __syncthreads();
+  sum = (red[0] + red[1]) + (red[2] + red[3]);
+  const float inv = 1.0f / sum;
+  uint16_t* pr = P + row * ldp;
+  for (int c = tid; c < cols; c += 256) pr[c] = T::from_f32(exp2f((sr[c] - mx) * cs) * inv);
+}
+}  // namespace
+
+extern "C" int vgen_softmax_rows(const float* S, int64_t rows, int32_t cols, int64_t lds,
+                                 float scale, void* P, int64_t ldp, int32_t dtype, void* stream) {
+  VGEN_REQUIRE(dtype == VGEN_BF16 || dtype == VGEN_F16, "softmax_rows: dtype");
+  VGEN_REQUIRE(rows >= 0 && cols > 0 && rows < (1LL << 31), "softmax_rows: sizes");
+  if (rows == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == VGEN_BF16)
+    hipLaunchKernelGGL(softmax_rows_kernel<BF16>, dim3((unsigned)rows), dim3(256), 0, s, S, cols,
+                       lds, scale, (uint16_t*)P, ldp);
+  else
+    hipLaunchKernelGGL(softmax_rows_kernel<F16>, dim3((unsigned)rows), dim3(256), 0, s, S, cols,
+                       lds, scale, (uint16_t*)P, ldp);
+  return vgen_check_launch("softmax_rows");
+}

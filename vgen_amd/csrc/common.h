@@ -1,0 +1,101 @@
+// common.h — shared device helpers for the gfx950 kernels of libvgen_hip.so.
+// CDNA4 only: wave64, MFMA 16x16x32 (16-bit in / fp32 accumulate), 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/vgen_hip.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+// ---- 16-bit storage types -------------------------------------------------------------
+struct BF16 {
+  static constexpr int kEnum = VGEN_BF16;
+  static __device__ __forceinline__ float to_f32(uint16_t b) {
+    return __uint_as_float(((uint32_t)b) << 16);
+  }
+  // round-to-nearest-even, NaN kept quiet
+  static __device__ __forceinline__ uint16_t from_f32(float f) {
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40u);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+  }
+  static __device__ __forceinline__ f32x4 mfma32(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                   __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 mfma16(u32x2 a, u32x2 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(__builtin_bit_cast(s16x4_t, a),
+                                                     __builtin_bit_cast(s16x4_t, b), c, 0, 0, 0);
+  }
+};
+
+struct F16 {
+  static constexpr int kEnum = VGEN_F16;
+  static __device__ __forceinline__ float to_f32(uint16_t b) {
+    return (float)__builtin_bit_cast(_Float16, b);
+  }
+  static __device__ __forceinline__ uint16_t from_f32(float f) {
+    return __builtin_bit_cast(uint16_t, (_Float16)f);
+  }
+  static __device__ __forceinline__ f32x4 mfma32(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
+                                                  __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
+  }
+  static __device__ __forceinline__ f32x4 mfma16(u32x2 a, u32x2 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(__builtin_bit_cast(f16x4_t, a),
+                                                 __builtin_bit_cast(f16x4_t, b), c, 0, 0, 0);
+  }
+};
+
+template <typename T>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  return (uint32_t)T::from_f32(lo) | ((uint32_t)T::from_f32(hi) << 16);
+}
+
+template <typename T>
+__device__ __forceinline__ u32x2 pack4(float a, float b, float c, float d) {
+  u32x2 r;
+  r.x = pack2<T>(a, b);
+  r.y = pack2<T>(c, d);
+  return r;
+}
+
+// ---- wave64 reductions ----------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// ---- host-side error plumbing (defined in cabi.cpp) -------------------------------------
+void vgen_set_error(const char* fmt, ...);
+int vgen_check_launch(const char* what);
+
+#define VGEN_REQUIRE(cond, ...)       \
+  do {                                \
+    if (!(cond)) {                    \
+      vgen_set_error(__VA_ARGS__);    \
+      return VGEN_E_BADARG;           \
+    }                                 \
+  } while (0)
+
+static inline bool vgen_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }

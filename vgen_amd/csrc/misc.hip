@@ -1,0 +1,262 @@
+// misc.hip — small HBM-bound elementwise / layout kernels of the sampling path
+// (reference call sites in include/vgen_hip.h).
+#include "common.h"
+
+namespace {
+
+template <typename T>
+__global__ __launch_bounds__(256) void act_cast_kernel(const float* __restrict__ x,
+                                                       uint16_t* __restrict__ y, int64_t n,
+                                                       int act) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float v = x[i];
+  if (act == 1) v = silu_f(v);
+  y[i] = T::from_f32(v);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void timestep_embedding_kernel(const float* __restrict__ t, int B,
+                                                                 int dim,
+                                                                 uint16_t* __restrict__ out) {
+  const int half = dim / 2;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * half) return;
+  const int b = i / half, k = i - b * half;
+  // torch.pow(10000, -arange(half)/half) in fp32, then outer product with t (util.py:184-187)
+  const float w = powf(10000.0f, -((float)k / (float)half));
+  const float arg = t[b] * w;
+  out[(int64_t)b * dim + k] = T::from_f32(cosf(arg));
+  out[(int64_t)b * dim + half + k] = T::from_f32(sinf(arg));
+  if ((dim & 1) && k == 0) out[(int64_t)b * dim + dim - 1] = T::from_f32(0.f);
+}
+
+struct SrcGeom {
+  int Fi, C, H, W;
+  int64_t s_bo, s_fi, s_c, s_y, s_x;
+};
+
+__device__ __forceinline__ int64_t src_off(const SrcGeom& g, int64_t img, int c, int y, int x) {
+  return (img / g.Fi) * g.s_bo + (img % g.Fi) * g.s_fi + (int64_t)c * g.s_c + (int64_t)y * g.s_y +
+         (int64_t)x * g.s_x;
+}
+
+// one thread per (output row, tap): writes Cin consecutive 16-bit values; pad columns zeroed by
+// the threads with tap >= 9.
+template <typename T>
+__global__ __launch_bounds__(256) void im2col3x3_small_kernel(const float* __restrict__ src,
+                                                              SrcGeom g, int64_t M, int Kpad,
+                                                              uint16_t* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int slots = (Kpad + g.C - 1) / g.C;  // taps + padding slots of C columns
+  const int64_t m = idx / slots;
+  const int tap = (int)(idx - m * slots);
+  if (m >= M) return;
+  const int hw = g.H * g.W;
+  const int64_t img = m / hw;
+  const int rem = (int)(m - img * hw);
+  const int y = rem / g.W, x = rem - y * g.W;
+  uint16_t* o = out + m * Kpad + tap * g.C;
+  bool inb = false;
+  int iy = 0, ix = 0;
+  if (tap < 9) {
+    iy = y + tap / 3 - 1;
+    ix = x + tap % 3 - 1;
+    inb = iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
+  }
+  for (int c = 0; c < g.C; ++c) {
+    if (tap * g.C + c >= Kpad) break;
+    float v = 0.f;
+    if (inb) v = src[src_off(g, img, c, iy, ix)];
+    o[c] = T::from_f32(v);
+  }
+}
+
+__global__ __launch_bounds__(256) void pointwise_small_kernel(const float* __restrict__ src,
+                                                              SrcGeom g, int64_t P,
+                                                              const float* __restrict__ Wm,
+                                                              const float* __restrict__ b, int Cout,
+                                                              float* __restrict__ dst, SrcGeom d) {
+  const int64_t pidx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (pidx >= P) return;
+  const int hw = g.H * g.W;
+  const int64_t img = pidx / hw;
+  const int rem = (int)(pidx - img * hw);
+  const int y = rem / g.W, x = rem - y * g.W;
+  float in[16];
+  for (int c = 0; c < g.C; ++c) in[c] = src[src_off(g, img, c, y, x)];
+  for (int co = 0; co < Cout; ++co) {
+    float acc = b ? b[co] : 0.f;
+    for (int c = 0; c < g.C; ++c) acc += Wm[co * g.C + c] * in[c];
+    dst[src_off(d, img, co, y, x)] = acc;
+  }
+}
+
+// CFG combine + DDIM update; arithmetic order mirrors diffusion_ddim.py:157-162,194-197,230-240.
+// FMA contraction is disabled so every product / sum is rounded to fp32 exactly like the
+// reference's separate torch elementwise kernels.
+__global__ __launch_bounds__(256) void cfg_ddim_step_kernel(
+    const float* __restrict__ xt, const float* __restrict__ y, const float* __restrict__ u,
+    const float* __restrict__ noise, const float* __restrict__ coef, float guide, int use_guide,
+    int mean_type, int64_t per_b, int64_t total, float* __restrict__ xt_1,
+    float* __restrict__ x0_out) {
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const float* cf = coef + (i / per_b) * 7;
+  const float x = xt[i];
+  float out = y[i];
+  if (use_guide) {
+    const float uu = u[i];
+    const float diff = out - uu;
+    const float sc = guide * diff;
+    out = uu + sc;
+  }
+  float x0;
+  if (mean_type == 2) {
+    x0 = out;
+  } else {
+    const float t0 = cf[0] * x;
+    const float t1 = cf[1] * out;
+    x0 = t0 - t1;
+  }
+  const float t2 = cf[2] * x;
+  const float num = t2 - x0;
+  const float eps = num / cf[3];
+  const float ap = cf[4], sg = cf[5], mk = cf[6];
+  const float sg2 = sg * sg;
+  const float om = 1.0f - ap;
+  const float dir_c = sqrtf(om - sg2);
+  const float direction = dir_c * eps;
+  const float lead = sqrtf(ap) * x0;
+  float r = lead + direction;
+  if (noise) {
+    const float ms = mk * sg;
+    const float nz = ms * noise[i];
+    r = r + nz;
+  }
+  xt_1[i] = r;
+  if (x0_out) x0_out[i] = x0;
+}
+
+__global__ __launch_bounds__(256) void gaussian_sample_kernel(const float* __restrict__ moments,
+                                                              const float* __restrict__ noise,
+                                                              int zc, int64_t HW, int64_t total,
+                                                              float scale, float* __restrict__ z) {
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;  // output index [img][c][p]
+  if (i >= total) return;
+  const int64_t p = i % HW;
+  const int64_t t = i / HW;
+  const int c = (int)(t % zc);
+  const int64_t img = t / zc;
+  const float* mrow = moments + (img * HW + p) * (2 * zc);
+  const float mean = mrow[c];
+  float logvar = mrow[zc + c];
+  logvar = fminf(fmaxf(logvar, -30.0f), 20.0f);
+  const float stdv = expf(0.5f * logvar);
+  const float s = stdv * noise[i];
+  const float v = mean + s;
+  z[i] = scale * v;
+}
+
+}  // namespace
+
+extern "C" int vgen_act_cast(const float* x, void* y, int64_t n, int32_t act, int32_t dtype,
+                             void* stream) {
+  VGEN_REQUIRE(dtype == VGEN_BF16 || dtype == VGEN_F16, "act_cast: dtype");
+  if (n <= 0) return 0;
+  const int64_t grid = (n + 255) / 256;
+  VGEN_REQUIRE(grid < (1LL << 31), "act_cast: n too large");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == VGEN_BF16)
+    hipLaunchKernelGGL(act_cast_kernel<BF16>, dim3((unsigned)grid), dim3(256), 0, s, x,
+                       (uint16_t*)y, n, act);
+  else
+    hipLaunchKernelGGL(act_cast_kernel<F16>, dim3((unsigned)grid), dim3(256), 0, s, x,
+                       (uint16_t*)y, n, act);
+  return vgen_check_launch("act_cast");
+}
+
+extern "C" int vgen_timestep_embedding(const float* t, int32_t B, int32_t dim, void* out,
+                                       int32_t dtype, void* stream) {
+  VGEN_REQUIRE(dtype == VGEN_BF16 || dtype == VGEN_F16, "timestep_embedding: dtype");
+  VGEN_REQUIRE(B > 0 && dim >= 2, "timestep_embedding: sizes");
+  const int n = B * (dim / 2);
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == VGEN_BF16)
+    hipLaunchKernelGGL(timestep_embedding_kernel<BF16>, dim3((n + 255) / 256), dim3(256), 0, s, t,
+                       B, dim, (uint16_t*)out);
+  else
+    hipLaunchKernelGGL(timestep_embedding_kernel<F16>, dim3((n + 255) / 256), dim3(256), 0, s, t,
+                       B, dim, (uint16_t*)out);
+  return vgen_check_launch("timestep_embedding");
+}
+
+extern "C" int vgen_im2col3x3_small(const float* src, int64_t nimg, int32_t Fi, int32_t Cin,
+                                    int32_t H, int32_t W, int64_t s_bo, int64_t s_fi, int64_t s_c,
+                                    int64_t s_y, int64_t s_x, void* out, int32_t Kpad,
+                                    int32_t dtype, void* stream) {
+  VGEN_REQUIRE(dtype == VGEN_BF16 || dtype == VGEN_F16, "im2col: dtype");
+  VGEN_REQUIRE(Cin > 0 && Cin <= 16 && Kpad % 64 == 0 && Kpad >= 9 * Cin && Fi > 0,
+               "im2col: Cin=%d Kpad=%d", Cin, Kpad);
+  const SrcGeom g{Fi, Cin, H, W, s_bo, s_fi, s_c, s_y, s_x};
+  const int64_t M = nimg * H * W;
+  const int slots = (Kpad + Cin - 1) / Cin;
+  const int64_t total = M * slots;
+  if (total <= 0) return 0;
+  const int64_t grid = (total + 255) / 256;
+  VGEN_REQUIRE(grid < (1LL << 31), "im2col: too large");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == VGEN_BF16)
+    hipLaunchKernelGGL(im2col3x3_small_kernel<BF16>, dim3((unsigned)grid), dim3(256), 0, s, src, g,
+                       M, Kpad, (uint16_t*)out);
+  else
+    hipLaunchKernelGGL(im2col3x3_small_kernel<F16>, dim3((unsigned)grid), dim3(256), 0, s, src, g,
+                       M, Kpad, (uint16_t*)out);
+  return vgen_check_launch("im2col3x3_small");
+}
+
+extern "C" int vgen_pointwise_small(const float* src, int64_t nimg, int32_t Fi, int32_t Cin,
+                                    int32_t H, int32_t W, int64_t s_bo, int64_t s_fi, int64_t s_c,
+                                    int64_t s_y, int64_t s_x, const float* Wm, const float* b,
+                                    int32_t Cout, float* dst, int64_t d_bo, int64_t d_fi,
+                                    int64_t d_c, int64_t d_y, int64_t d_x, void* stream) {
+  VGEN_REQUIRE(Cin > 0 && Cin <= 16 && Cout > 0 && Cout <= 16 && Fi > 0, "pointwise_small: C");
+  const SrcGeom g{Fi, Cin, H, W, s_bo, s_fi, s_c, s_y, s_x};
+  const SrcGeom d{Fi, Cout, H, W, d_bo, d_fi, d_c, d_y, d_x};
+  const int64_t P = nimg * H * W;
+  if (P <= 0) return 0;
+  const int64_t grid = (P + 255) / 256;
+  VGEN_REQUIRE(grid < (1LL << 31), "pointwise_small: too large");
+  hipLaunchKernelGGL(pointwise_small_kernel, dim3((unsigned)grid), dim3(256), 0,
+                     (hipStream_t)stream, src, g, P, Wm, b, Cout, dst, d);
+  return vgen_check_launch("pointwise_small");
+}
+
+extern "C" int vgen_cfg_ddim_step(const float* xt, const float* y, const float* u,
+                                  const float* noise, const float* coef, float guide,
+                                  int32_t use_guide, int32_t mean_type, int64_t B, int64_t per_b,
+                                  float* xt_1, float* x0_out, void* stream) {
+  VGEN_REQUIRE(mean_type >= 0 && mean_type <= 2, "cfg_ddim_step: mean_type");
+  VGEN_REQUIRE(!use_guide || u != nullptr, "cfg_ddim_step: guidance needs u");
+  const int64_t total = B * per_b;
+  if (total <= 0) return 0;
+  const int64_t grid = (total + 255) / 256;
+  VGEN_REQUIRE(grid < (1LL << 31), "cfg_ddim_step: too large");
+  hipLaunchKernelGGL(cfg_ddim_step_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
+                     xt, y, u, noise, coef, guide, use_guide, mean_type, per_b, total, xt_1, x0_out);
+  return vgen_check_launch("cfg_ddim_step");
+}
+
+extern "C" int vgen_gaussian_sample(const float* moments, const float* noise, int64_t nimg,
+                                    int32_t zc, int64_t HW, float scale, float* z, void* stream) {
+  VGEN_REQUIRE(zc > 0 && HW > 0, "gaussian_sample: sizes");
+  const int64_t total = nimg * zc * HW;
+  if (total <= 0) return 0;
+  const int64_t grid = (total + 255) / 256;
+  VGEN_REQUIRE(grid < (1LL << 31), "gaussian_sample: too large");
+  hipLaunchKernelGGL(gaussian_sample_kernel, dim3((unsigned)grid), dim3(256), 0,
+                     (hipStream_t)stream, moments, noise, zc, HW, total, scale, z);
+  return vgen_check_launch("gaussian_sample");
+}

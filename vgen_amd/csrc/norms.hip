@@ -1,0 +1,349 @@
+// norms.hip — GroupNorm(+SiLU) and LayerNorm, fp32 in -> 16-bit out (HBM-bound kernels).
+//
+// GroupNorm runs as three launches over channels-last rows [nb*S, C]:
+//   1. gn_stats   : grid (nsplit, nb); every block streams a contiguous slab of rows with
+//                   16-byte loads (all channels of a row are contiguous -> fully coalesced),
+//                   keeps per-channel partial sums in registers, folds channels -> groups
+//                   through LDS in a fixed order and writes (count, mean, M2) per group.
+//   2. gn_finalize: grid (nb); Chan-combines the nsplit partials per group -> (mean, rstd).
+//   3. gn_apply   : same streaming pattern; y = act(x * scale_c + shift_c) with
+//                   scale_c = gamma_c * rstd_g, shift_c = beta_c - mean_g * scale_c held in
+//                   registers; 8-byte 16-bit stores.
+// The reduction order is fixed (no atomics) so results are run-to-run deterministic.
+// The input row is the virtual concat [x1 | x2] (decoder skip connections).
+#include "common.h"
+
+namespace {
+
+constexpr int GN_THREADS = 256;
+constexpr int GN_MAX_SLOTS = 3;   // float4 slots per thread -> C <= 3072
+constexpr int GN_G = 32;          // groups supported per launch (reference always uses 32)
+
+struct GnGeom {
+  int C, C1, C2;
+  int nslots;       // C / 4
+  int tpr;          // threads per row pass
+  int rpb;          // rows in flight per block pass
+  int spt;          // slots per thread
+  int cpg;          // channels per group
+};
+
+__device__ __forceinline__ GnGeom gn_geom(int C1, int C2, int groups) {
+  GnGeom g;
+  g.C1 = C1;
+  g.C2 = C2;
+  g.C = C1 + C2;
+  g.nslots = g.C >> 2;
+  if (g.nslots <= GN_THREADS) {
+    g.tpr = g.nslots;
+    g.rpb = GN_THREADS / g.nslots;
+    g.spt = 1;
+  } else {
+    g.tpr = GN_THREADS;
+    g.rpb = 1;
+    g.spt = (g.nslots + GN_THREADS - 1) / GN_THREADS;
+  }
+  g.cpg = g.C / groups;
+  return g;
+}
+
+__device__ __forceinline__ f32x4 gn_load(const float* x1, const float* x2, const GnGeom& g,
+                                         int64_t row, int c) {
+  if (c < g.C1) return *(const f32x4*)(x1 + row * g.C1 + c);
+  return *(const f32x4*)(x2 + row * g.C2 + (c - g.C1));
+}
+
+// ws layout: part[nb][nsplit][groups][3] (count, mean, M2) then stat[nb][groups][2] (mean, rstd)
+__global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(
+    const float* __restrict__ x1, int C1, const float* __restrict__ x2, int C2, int64_t S,
+    int groups, int nsplit, float* __restrict__ part) {
+  __shared__ float red[2][3072];  // [sum|sumsq][rowlane * C + c]  (rpb * C <= 1024 when rpb > 1)
+  const GnGeom g = gn_geom(C1, C2, groups);
+  const int tid = threadIdx.x;
+  const int split = blockIdx.x;
+  const int64_t nb = blockIdx.y;
+  const int64_t rows_per = (S + nsplit - 1) / nsplit;
+  const int64_t r_begin = (int64_t)split * rows_per;
+  const int64_t r_end = min(S, r_begin + rows_per);
+  const int rowlane = tid / g.tpr;
+  const int slot0 = tid - rowlane * g.tpr;
+  const bool active = rowlane < g.rpb;
+
+  f32x4 s[GN_MAX_SLOTS], ss[GN_MAX_SLOTS];
+#pragma unroll
+  for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+    s[k] = f32x4{0, 0, 0, 0};
+    ss[k] = f32x4{0, 0, 0, 0};
+  }
+  if (active) {
+    for (int64_t r = r_begin + rowlane; r < r_end; r += g.rpb) {
+      const int64_t row = nb * S + r;
+#pragma unroll
+      for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+        const int slot = slot0 + k * GN_THREADS;
+        if (k < g.spt && slot < g.nslots) {
+          const f32x4 v = gn_load(x1, x2, g, row, slot * 4);
+          s[k] += v;
+          ss[k] += v * v;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+      const int slot = slot0 + k * GN_THREADS;
+      if (k < g.spt && slot < g.nslots) {
+        const int o = rowlane * g.C + slot * 4;
+        *(f32x4*)&red[0][o] = s[k];
+        *(f32x4*)&red[1][o] = ss[k];
+      }
+    }
+  }
+  __syncthreads();
+  if (tid < groups) {
+    float a = 0.f, b = 0.f;
+    for (int rl = 0; rl < g.rpb; ++rl) {
+      const int o = rl * g.C + tid * g.cpg;
+      for (int c = 0; c < g.cpg; ++c) {
+        a += red[0][o + c];
+        b += red[1][o + c];
+      }
+    }
+    const float n = (float)((r_end > r_begin ? (r_end - r_begin) : 0) * g.cpg);
+    const float mean = n > 0.f ? a / n : 0.f;
+    const float m2 = n > 0.f ? fmaxf(b - a * mean, 0.f) : 0.f;
+    float* o = part + ((nb * nsplit + split) * groups + tid) * 3;
+    o[0] = n;
+    o[1] = mean;
+    o[2] = m2;
+  }
+}
+
+__global__ __launch_bounds__(GN_THREADS) void gn_finalize_kernel(const float* __restrict__ part,
+                                                                 int groups, int nsplit, float eps,
+                                                                 float* __restrict__ stat) {
+  // 8 lanes per group; lane j folds splits j, j+8, ... sequentially, then an 8-lane tree.
+  const int tid = threadIdx.x;
+  const int grp = tid >> 3;
+  const int j = tid & 7;
+  const int64_t nb = blockIdx.x;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  if (grp < groups) {
+    for (int sp = j; sp < nsplit; sp += 8) {
+      const float* p = part + ((nb * nsplit + sp) * groups + grp) * 3;
+      const float nb_ = p[0], mb = p[1], m2b = p[2];
+      if (nb_ > 0.f) {
+        const float nt = n + nb_;
+        const float d = mb - mean;
+        mean += d * (nb_ / nt);
+        m2 += m2b + d * d * (n * nb_ / nt);
+        n = nt;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 1; o < 8; o <<= 1) {
+    const float n2 = __shfl_xor(n, o, 64), mean2 = __shfl_xor(mean, o, 64),
+                m22 = __shfl_xor(m2, o, 64);
+    const float nt = n + n2;
+    if (nt > 0.f) {
+      const float d = mean2 - mean;
+      const float w = n2 / nt;
+      m2 = m2 + m22 + d * d * (n * w);
+      mean = mean + d * w;
+    }
+    n = nt;
+  }
+  if (grp < groups && j == 0) {
+    const float var = n > 0.f ? m2 / n : 0.f;
+    stat[(nb * groups + grp) * 2 + 0] = mean;
+    stat[(nb * groups + grp) * 2 + 1] = 1.0f / sqrtf(var + eps);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(
+    const float* __restrict__ x1, int C1, const float* __restrict__ x2, int C2, int64_t S,
+    int groups, int nsplit, const float* __restrict__ stat, const float* __restrict__ gamma,
+    const float* __restrict__ beta, int silu, uint16_t* __restrict__ y,
+    uint16_t* __restrict__ raw) {
+  const GnGeom g = gn_geom(C1, C2, groups);
+  const int tid = threadIdx.x;
+  const int split = blockIdx.x;
+  const int64_t nb = blockIdx.y;
+  const int64_t rows_per = (S + nsplit - 1) / nsplit;
+  const int64_t r_begin = (int64_t)split * rows_per;
+  const int64_t r_end = min(S, r_begin + rows_per);
+  const int rowlane = tid / g.tpr;
+  const int slot0 = tid - rowlane * g.tpr;
+  if (rowlane >= g.rpb) return;
+
+  f32x4 sc[GN_MAX_SLOTS], sh[GN_MAX_SLOTS];
+#pragma unroll
+  for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+    const int slot = slot0 + k * GN_THREADS;
+    if (k < g.spt && slot < g.nslots) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = slot * 4 + e;
+        const int grp = c / g.cpg;
+        const float mean = stat[(nb * groups + grp) * 2 + 0];
+        const float rstd = stat[(nb * groups + grp) * 2 + 1];
+        const float a = gamma[c] * rstd;
+        sc[k][e] = a;
+        sh[k][e] = beta[c] - mean * a;
+      }
+    }
+  }
+  for (int64_t r = r_begin + rowlane; r < r_end; r += g.rpb) {
+    const int64_t row = nb * S + r;
+#pragma unroll
+    for (int k = 0; k < GN_MAX_SLOTS; ++k) {
+      const int slot = slot0 + k * GN_THREADS;
+      if (k < g.spt && slot < g.nslots) {
+        const f32x4 v = gn_load(x1, x2, g, row, slot * 4);
+        f32x4 o = v * sc[k] + sh[k];
+        if (silu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = silu_f(o[e]);
+        }
+        *(u32x2*)(y + row * g.C + slot * 4) = pack4<T>(o.x, o.y, o.z, o.w);
+        if (raw) *(u32x2*)(raw + row * g.C + slot * 4) = pack4<T>(v.x, v.y, v.z, v.w);
+      }
+    }
+  }
+}
+
+int gn_nsplit(int64_t nb, int64_t S) {
+  // aim for >= ~1024 blocks overall, >= 32 rows per block, <= 512 splits per batch
+  int64_t want = (1024 + nb - 1) / nb;
+  int64_t by_rows = (S + 31) / 32;
+  int64_t ns = want < by_rows ? want : by_rows;
+  if (ns < 1) ns = 1;
+  if (ns > 512) ns = 512;
+  return (int)ns;
+}
+
+// ---- LayerNorm: one wave per row, two-pass from registers --------------------------------
+constexpr int LN_MAX_SLOTS = 8;  // d <= 2048
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t M,
+                                                        int d, float eps,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        uint16_t* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int nslots = d >> 2;
+  const float* xr = x + row * d;
+  f32x4 v[LN_MAX_SLOTS];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAX_SLOTS; ++k) {
+    const int slot = lane + 64 * k;
+    v[k] = f32x4{0, 0, 0, 0};
+    if (slot < nslots) {
+      v[k] = *(const f32x4*)(xr + slot * 4);
+      s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
+    }
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < LN_MAX_SLOTS; ++k) {
+    const int slot = lane + 64 * k;
+    if (slot < nslots) {
+      const f32x4 c = v[k] - mean;
+      q += (c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+  uint16_t* yr = y + row * d;
+#pragma unroll
+  for (int k = 0; k < LN_MAX_SLOTS; ++k) {
+    const int slot = lane + 64 * k;
+    if (slot < nslots) {
+      const f32x4 ga = *(const f32x4*)(gamma + slot * 4);
+      const f32x4 be = *(const f32x4*)(beta + slot * 4);
+      const f32x4 o = (v[k] - mean) * rstd * ga + be;
+      *(u32x2*)(yr + slot * 4) = pack4<T>(o.x, o.y, o.z, o.w);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" size_t vgen_groupnorm_ws_bytes(int64_t nb, int64_t S) {
+  const int ns = gn_nsplit(nb, S);
+  return (size_t)(nb * ns * GN_G * 3 + nb * GN_G * 2) * sizeof(float);
+}
+
+extern "C" int vgen_groupnorm(const float* x1, int32_t C1, const float* x2, int32_t C2,
+                              int64_t nb, int64_t S, int32_t groups, float eps,
+                              const float* gamma, const float* beta, int32_t silu, void* y,
+                              void* raw, int32_t dtype, float* ws, size_t ws_bytes,
+                              void* stream) {
+  const int C = C1 + C2;
+  VGEN_REQUIRE(dtype == VGEN_BF16 || dtype == VGEN_F16, "groupnorm: dtype");
+  VGEN_REQUIRE(groups > 0 && groups <= GN_G && C % groups == 0, "groupnorm: C=%d groups=%d", C,
+               groups);
+  VGEN_REQUIRE(C1 > 0 && C1 % 4 == 0 && C2 >= 0 && C2 % 4 == 0 && C <= 3072,
+               "groupnorm: C1=%d C2=%d (need %%4, total <= 3072)", C1, C2);
+  VGEN_REQUIRE(C2 == 0 || x2 != nullptr, "groupnorm: x2 null with C2 > 0");
+  VGEN_REQUIRE(vgen_aligned16(x1) && vgen_aligned16(x2) && vgen_aligned16(y) &&
+                   vgen_aligned16(raw) && vgen_aligned16(ws),
+               "groupnorm: alignment");
+  VGEN_REQUIRE(nb > 0 && S > 0 && nb <= 65535, "groupnorm: nb=%lld S=%lld", (long long)nb,
+               (long long)S);
+  if (ws_bytes < vgen_groupnorm_ws_bytes(nb, S)) {
+    vgen_set_error("groupnorm: workspace %zu < %zu", ws_bytes, vgen_groupnorm_ws_bytes(nb, S));
+    return VGEN_E_WORKSPACE;
+  }
+  // rpb * C must fit the LDS staging of gn_stats (3072 floats per plane)
+  const int nslots = C / 4;
+  const int rpb = nslots <= GN_THREADS ? GN_THREADS / nslots : 1;
+  VGEN_REQUIRE(rpb * C <= 3072, "groupnorm: internal LDS bound");
+  const int ns = gn_nsplit(nb, S);
+  float* part = ws;
+  float* stat = ws + nb * ns * GN_G * 3;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)ns, (unsigned)nb);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_THREADS), 0, s, x1, C1, x2, C2, S, groups, ns,
+                     part);
+  int rc = vgen_check_launch("gn_stats");
+  if (rc) return rc;
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)nb), dim3(GN_THREADS), 0, s, part, groups,
+                     ns, eps, stat);
+  rc = vgen_check_launch("gn_finalize");
+  if (rc) return rc;
+  if (dtype == VGEN_BF16) {
+    hipLaunchKernelGGL(gn_apply_kernel<BF16>, grid, dim3(GN_THREADS), 0, s, x1, C1, x2, C2, S,
+                       groups, ns, stat, gamma, beta, silu, (uint16_t*)y, (uint16_t*)raw);
+  } else {
+    hipLaunchKernelGGL(gn_apply_kernel<F16>, grid, dim3(GN_THREADS), 0, s, x1, C1, x2, C2, S,
+                       groups, ns, stat, gamma, beta, silu, (uint16_t*)y, (uint16_t*)raw);
+  }
+  return vgen_check_launch("gn_apply");
+}
+
+extern "C" int vgen_layernorm(const float* x, int64_t M, int32_t d, float eps, const float* gamma,
+                              const float* beta, void* y, int32_t dtype, void* stream) {
+  VGEN_REQUIRE(dtype == VGEN_BF16 || dtype == VGEN_F16, "layernorm: dtype");
+  VGEN_REQUIRE(d > 0 && d % 4 == 0 && d <= 64 * 4 * LN_MAX_SLOTS, "layernorm: d=%d", d);
+  VGEN_REQUIRE(vgen_aligned16(x) && vgen_aligned16(y) && vgen_aligned16(gamma) &&
+                   vgen_aligned16(beta),
+               "layernorm: alignment");
+  if (M <= 0) return 0;
+  const int64_t grid = (M + 3) / 4;
+  VGEN_REQUIRE(grid < (1LL << 31), "layernorm: M too large");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == VGEN_BF16) {
+    hipLaunchKernelGGL(layernorm_kernel<BF16>, dim3((unsigned)grid), dim3(256), 0, s, x, M, d, eps,
+                       gamma, beta, (uint16_t*)y);
+  } else {
+    hipLaunchKernelGGL(layernorm_kernel<F16>, dim3((unsigned)grid), dim3(256), 0, s, x, M, d, eps,
+                       gamma, beta, (uint16_t*)y);
+  }
+  return vgen_check_launch("layernorm");
+}

@@ -1,0 +1,215 @@
+"""DiffusionDDIM — sampling side of the reference's DDIM diffusion, MI355X-native.
+
+Interface parity (reference: tools/modules/diffusions/diffusion_ddim.py:28-78 ctor,
+:147-206 p_mean_variance, :208-241 ddim_sample, :243-254 ddim_sample_loop,
+:256-288 ddim_reverse_sample(_loop), :91-97 q_sample, :507-511 _scale_timesteps):
+same registry name, same constructor keywords, same method signatures / return values, the
+sampler still accepts ANY `model(xt, t, **kwargs)` callable.
+
+What is different underneath:
+  * the float64 schedule tables are cast to fp32 once and cached per device (the reference
+    re-uploads a float64 table on every `_i()` call, diffusion_ddim.py:13-16),
+  * classifier-free guidance + the v/eps/x0 algebra + the DDIM update are ONE fused HIP kernel
+    (vgen_cfg_ddim_step) that reproduces the reference's fp32 operation order bit for bit,
+  * when the model exposes `forward_units` (vgen_amd.unet) the cond/uncond pair is evaluated as
+    one batch (weights stream from HBM once per step), and when a UnitPartition is attached the
+    units are spread over the ranks with a single all-gather per step (vgen_amd/parallel.py).
+Training-only members of the reference class (loss, VLB, PLMS, DDPM p_sample) are out of scope
+(SURVEY.md §8a / §2 row 1).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from .schedules import beta_schedule
+
+_MEAN = {"eps": 0, "v": 1, "x0": 2}
+# rows of the per-device fp32 table
+_AC, _SQRT_AC, _SQRT_1M, _SQRT_RECIP, _SQRT_RECIPM1, _AC_NEXT = range(6)
+
+
+class DiffusionDDIM(object):
+    def __init__(self, schedule="linear_sd", schedule_param={}, mean_type="eps",
+                 var_type="learned_range", loss_type="mse", epsilon=1e-12,
+                 rescale_timesteps=False, noise_strength=0.0, **kwargs):
+        assert mean_type in ["x0", "x_{t-1}", "eps", "v"]
+        assert var_type in ["learned", "learned_range", "fixed_large", "fixed_small"]
+        betas = beta_schedule(schedule, **schedule_param)
+        assert min(betas) > 0 and max(betas) <= 1
+        if not isinstance(betas, torch.DoubleTensor):
+            betas = torch.tensor(betas, dtype=torch.float64)
+        self.betas = betas
+        self.num_timesteps = len(betas)
+        self.mean_type, self.var_type, self.loss_type = mean_type, var_type, loss_type
+        self.epsilon, self.rescale_timesteps, self.noise_strength = epsilon, rescale_timesteps, noise_strength
+
+        alphas = 1 - self.betas
+        self.alphas_cumprod = torch.cumprod(alphas, dim=0)
+        self.alphas_cumprod_prev = torch.cat([alphas.new_ones([1]), self.alphas_cumprod[:-1]])
+        self.alphas_cumprod_next = torch.cat([self.alphas_cumprod[1:], alphas.new_zeros([1])])
+        self.sqrt_alphas_cumprod = torch.sqrt(self.alphas_cumprod)
+        self.sqrt_one_minus_alphas_cumprod = torch.sqrt(1.0 - self.alphas_cumprod)
+        self.log_one_minus_alphas_cumprod = torch.log(1.0 - self.alphas_cumprod)
+        self.sqrt_recip_alphas_cumprod = torch.sqrt(1.0 / self.alphas_cumprod)
+        self.sqrt_recipm1_alphas_cumprod = torch.sqrt(1.0 / self.alphas_cumprod - 1)
+        self.posterior_variance = betas * (1.0 - self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_log_variance_clipped = torch.log(self.posterior_variance.clamp(1e-20))
+        self.posterior_mean_coef1 = betas * torch.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
+        self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * torch.sqrt(alphas) / (1.0 - self.alphas_cumprod)
+
+        self._tab = {}
+        self.partition = None          # optional vgen_amd.parallel.UnitPartition
+        self.rng_parity = True         # draw the (unused when eta == 0) per-step noise like the reference
+
+    # -- tables ---------------------------------------------------------------------------------
+    def _table(self, device):
+        tab = self._tab.get(device)
+        if tab is None:
+            ac_ext = torch.cat([self.alphas_cumprod, self.alphas_cumprod.new_zeros([1])])
+            pad = lambda v: torch.cat([v, v.new_zeros([1])])
+            rows = [ac_ext, pad(self.sqrt_alphas_cumprod), pad(self.sqrt_one_minus_alphas_cumprod),
+                    pad(self.sqrt_recip_alphas_cumprod), pad(self.sqrt_recipm1_alphas_cumprod), ac_ext]
+            tab = torch.stack(rows).to(torch.float32).to(device)     # fp64 -> fp32 like `_i(...).to(x)`
+            self._tab[device] = tab
+        return tab
+
+    def _scale_timesteps(self, t):
+        if self.rescale_timesteps:
+            return t.float() * 1000.0 / self.num_timesteps
+        return t
+
+    # -- q(x_t | x_0) ---------------------------------------------------------------------------
+    def q_sample(self, x0, t, noise=None):
+        if noise is None:
+            noise = torch.randn_like(x0)
+            if self.noise_strength > 0:
+                b, c, f, _, _ = x0.shape
+                noise = noise + self.noise_strength * torch.randn(b, c, f, 1, 1, device=x0.device)
+        tab = self._table(x0.device)
+        shape = (x0.size(0),) + (1,) * (x0.ndim - 1)
+        return tab[_SQRT_AC][t].view(shape) * x0 + tab[_SQRT_1M][t].view(shape) * noise
+
+    # -- model evaluation -------------------------------------------------------------------------
+    def _eval_model(self, xt, t, model, model_kwargs, guide_scale):
+        ts = self._scale_timesteps(t)
+        if guide_scale is None:
+            return model(xt, ts, **model_kwargs), None
+        assert isinstance(model_kwargs, list) and len(model_kwargs) == 2
+        inner = getattr(model, "module", model)
+        if self.partition is not None:
+            y_out, u_out = self.partition.run_units(inner, xt, ts, model_kwargs)
+        elif hasattr(inner, "forward_units"):
+            y_out, u_out = inner.forward_units(xt, ts, model_kwargs)
+        else:
+            y_out = model(xt, ts, **model_kwargs[0])
+            u_out = model(xt, ts, **model_kwargs[1])
+        return y_out, u_out
+
+    def _x0_coefs(self, tab, t):
+        if self.mean_type == "v":
+            return tab[_SQRT_AC][t], tab[_SQRT_1M][t]
+        if self.mean_type == "eps":
+            return tab[_SQRT_RECIP][t], tab[_SQRT_RECIPM1][t]
+        if self.mean_type == "x0":
+            z = torch.zeros_like(tab[_AC][t])
+            return z, z
+        raise NotImplementedError("mean_type 'x_{t-1}' is not on the sampling path")
+
+    def _fused(self, xt, t, model, model_kwargs, guide_scale, alphas_prev, sigmas, mask, noise,
+               clamp, percentile, want_x0=True):
+        if clamp is not None or percentile is not None:
+            raise NotImplementedError("clamp / percentile are unused by the inference configs")
+        if self.var_type not in ("fixed_small", "fixed_large"):
+            raise NotImplementedError("learned variances are not on the sampling path")
+        y_out, u_out = self._eval_model(xt, t, model, model_kwargs, guide_scale)
+        tab = self._table(xt.device)
+        a0, a1 = self._x0_coefs(tab, t)
+        coef = torch.stack([a0, a1, tab[_SQRT_RECIP][t], tab[_SQRT_RECIPM1][t], alphas_prev, sigmas,
+                            mask], dim=1).contiguous()
+        xt32 = xt.float().contiguous()
+        y32 = y_out.float().contiguous()
+        u32 = None if u_out is None else u_out.float().contiguous()
+        return ops.backend().cfg_ddim_step(xt32, y32, u32, noise, coef,
+                                           0.0 if guide_scale is None else float(guide_scale),
+                                           guide_scale is not None, _MEAN[self.mean_type], want_x0)
+
+    # -- p(x_{t-1} | x_t) pieces used by the samplers ---------------------------------------------
+    @torch.no_grad()
+    def p_mean_variance(self, xt, t, model, model_kwargs={}, clamp=None, percentile=None, guide_scale=None):
+        """Returns (mu, var, log_var, x0) like the reference; x0 comes from the fused kernel."""
+        tab = self._table(xt.device)
+        one = torch.ones_like(tab[_AC][t])
+        _, x0 = self._fused(xt, t, model, model_kwargs, guide_scale, one, torch.zeros_like(one),
+                            torch.zeros_like(one), None, clamp, percentile)
+        shape = (xt.size(0),) + (1,) * (xt.ndim - 1)
+        g = lambda v: v.to(torch.float32).to(xt.device)[t].view(shape)
+        if self.var_type == "fixed_large":
+            var = g(torch.cat([self.posterior_variance[1:2], self.betas[1:]]))
+            log_var = torch.log(var)
+        else:
+            var = g(self.posterior_variance)
+            log_var = g(self.posterior_log_variance_clipped)
+        mu = g(self.posterior_mean_coef1) * x0 + g(self.posterior_mean_coef2) * xt
+        return mu, var, log_var, x0
+
+    @torch.no_grad()
+    def ddim_sample(self, xt, t, model, model_kwargs={}, clamp=None, percentile=None, condition_fn=None,
+                    guide_scale=None, ddim_timesteps=20, eta=0.0):
+        if condition_fn is not None:
+            raise NotImplementedError("classifier guidance (condition_fn) is unused by the inference configs")
+        stride = self.num_timesteps // ddim_timesteps
+        tab = self._table(xt.device)
+        # per-batch scalars, fp32, same expression order as diffusion_ddim.py:232-234
+        alphas = tab[_AC][t]
+        alphas_prev = tab[_AC][(t - stride).clamp(0)]
+        sigmas = eta * torch.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
+        mask = t.ne(0).float()
+        noise = None
+        if self.rng_parity or eta != 0.0:
+            noise = torch.randn_like(xt)             # drawn every step by the reference (:237)
+        if eta == 0.0:
+            noise = None                             # sigma == 0: the term is exactly +0
+        xt_1, x0 = self._fused(xt, t, model, model_kwargs, guide_scale, alphas_prev, sigmas, mask,
+                               noise if noise is None else noise.float().contiguous(), clamp, percentile)
+        return xt_1, x0
+
+    @torch.no_grad()
+    def ddim_sample_loop(self, noise, model, model_kwargs={}, clamp=None, percentile=None,
+                         condition_fn=None, guide_scale=None, ddim_timesteps=20, eta=0.0):
+        b = noise.size(0)
+        xt = noise
+        steps = (1 + torch.arange(0, self.num_timesteps, self.num_timesteps // ddim_timesteps)) \
+            .clamp(0, self.num_timesteps - 1).flip(0)
+        for step in steps:
+            t = torch.full((b,), int(step), dtype=torch.long, device=xt.device)
+            xt, _ = self.ddim_sample(xt, t, model, model_kwargs, clamp, percentile, condition_fn,
+                                     guide_scale, ddim_timesteps, eta)
+        return xt
+
+    @torch.no_grad()
+    def ddim_reverse_sample(self, xt, t, model, model_kwargs={}, clamp=None, percentile=None,
+                            guide_scale=None, ddim_timesteps=20):
+        """x_t -> x_{t+stride} along the deterministic DDIM ODE (diffusion_ddim.py:256-274):
+        mu = sqrt(a_next) * x0 + sqrt(1 - a_next) * eps — the same kernel with sigma = 0."""
+        stride = self.num_timesteps // ddim_timesteps
+        tab = self._table(xt.device)
+        alphas_next = tab[_AC_NEXT][(t + stride).clamp(0, self.num_timesteps)]
+        zero = torch.zeros_like(alphas_next)
+        mu, x0 = self._fused(xt, t, model, model_kwargs, guide_scale, alphas_next, zero, zero, None,
+                             clamp, percentile)
+        return mu, x0
+
+    @torch.no_grad()
+    def ddim_reverse_sample_loop(self, x0, model, model_kwargs={}, clamp=None, percentile=None,
+                                 guide_scale=None, ddim_timesteps=20):
+        b = x0.size(0)
+        xt = x0
+        steps = torch.arange(0, self.num_timesteps, self.num_timesteps // ddim_timesteps)
+        for step in steps:
+            t = torch.full((b,), int(step), dtype=torch.long, device=xt.device)
+            xt, _ = self.ddim_reverse_sample(xt, t, model, model_kwargs, clamp, percentile, guide_scale,
+                                             ddim_timesteps)
+        return xt

@@ -1,0 +1,279 @@
+"""Tensor-level wrappers over the C ABI of libvgen_hip.so.
+
+Every op takes torch tensors (device memory owned by PyTorch), marshals raw pointers / strides
+into the C structs of include/vgen_hip.h and enqueues the HIP kernels on the CURRENT torch
+stream (so the calls are capturable in a hipGraph via torch.cuda.graph).
+
+There is exactly one product backend (`HipBackend`).  `set_backend()` exists so the test-suite
+can inject the CPU emulator of the ABI (oracle/abi_emulator.py) and validate the host-side
+orchestration (weight packing, layouts, strides, call order) without a GPU; product code never
+does that, and a missing library / CPU tensor raises instead of falling back.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Optional
+
+import torch
+
+from . import lib as _lib
+
+_ENUM = {torch.bfloat16: _lib.VGEN_BF16, torch.float16: _lib.VGEN_F16, torch.float32: _lib.VGEN_F32}
+
+
+@dataclass
+class TapGemm:
+    """Argument block of vgen_tapgemm (see include/vgen_hip.h)."""
+    A: torch.Tensor                 # 2-D 16-bit view [rows, >=C1], unit inner stride
+    W: torch.Tensor                 # 2-D 16-bit [N, K]
+    M: int
+    N: int
+    C1: int
+    mode: int = _lib.TAP_LINEAR
+    taps: int = 1
+    Hi: int = 0
+    Wi: int = 0
+    Ho: int = 0
+    Wo: int = 0
+    stride: int = 1
+    pad_t: int = 1
+    pad_l: int = 1
+    ups: int = 0
+    F: int = 0
+    S: int = 0
+    A2: Optional[torch.Tensor] = None
+    C2: int = 0
+    bias: Optional[torch.Tensor] = None       # fp32 [N]
+    rowbias: Optional[torch.Tensor] = None    # fp32 2-D view [nbatch, >=N]
+    rows_per_rb: int = 0
+    residual: Optional[torch.Tensor] = None   # fp32 2-D view [M, >=N_out]
+    out_dtype: torch.dtype = torch.float32
+    epilogue: int = _lib.EPI_NONE
+    out: Optional[torch.Tensor] = None        # optional preallocated 2-D view [M, >=N_out]
+
+
+@dataclass
+class Attn:
+    """Argument block of vgen_attention.  q/k/v/out are tensors whose data_ptr() is the address
+    of element (bi=0, row=0, head=0, 0); all strides are in elements."""
+    q: torch.Tensor
+    k: torch.Tensor
+    v: torch.Tensor
+    out: torch.Tensor
+    heads: int
+    nq: int
+    nk: int
+    nbatch: int
+    inner: int
+    q_s: tuple  # (rs, bo, bi)
+    k_s: tuple
+    v_s: tuple
+    o_s: tuple
+    scale: float
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _mat(t: torch.Tensor, name: str):
+    if t.dim() != 2 or t.stride(1) != 1:
+        raise ValueError(f"{name}: expected a 2-D view with unit inner stride, got {tuple(t.shape)} "
+                         f"strides {t.stride()}")
+    return t
+
+
+class HipBackend:
+    name = "hip"
+
+    def __init__(self):
+        self.lib = _lib.load()
+
+    # -- helpers ---------------------------------------------------------------------------
+    @staticmethod
+    def _stream(t: torch.Tensor):
+        if not t.is_cuda:
+            raise _lib.VgenHipError(
+                "vgen_amd hot path needs device tensors (got %s); there is no CPU fallback" % t.device)
+        return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+    # -- norms -----------------------------------------------------------------------------
+    def groupnorm(self, x1, x2, nb, S, groups, eps, gamma, beta, silu, want_raw, dt):
+        C1 = x1.shape[1]
+        C2 = 0 if x2 is None else x2.shape[1]
+        rows = nb * S
+        assert x1.dtype == torch.float32 and x1.is_contiguous() and x1.shape[0] == rows
+        assert x2 is None or (x2.dtype == torch.float32 and x2.is_contiguous() and x2.shape[0] == rows)
+        y = torch.empty((rows, C1 + C2), dtype=dt, device=x1.device)
+        raw = torch.empty_like(y) if want_raw else None
+        nbytes = self.lib.vgen_groupnorm_ws_bytes(nb, S)
+        ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x1.device)
+        rc = self.lib.vgen_groupnorm(_ptr(x1), C1, _ptr(x2), C2, nb, S, groups, float(eps),
+                                     _ptr(gamma), _ptr(beta), int(bool(silu)), _ptr(y), _ptr(raw),
+                                     _ENUM[dt], _ptr(ws), nbytes, self._stream(x1))
+        _lib.check(rc, "vgen_groupnorm")
+        return y, raw
+
+    def layernorm(self, x, gamma, beta, eps, dt):
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+        y = torch.empty(x.shape, dtype=dt, device=x.device)
+        rc = self.lib.vgen_layernorm(_ptr(x), x.shape[0], x.shape[1], float(eps), _ptr(gamma),
+                                     _ptr(beta), _ptr(y), _ENUM[dt], self._stream(x))
+        _lib.check(rc, "vgen_layernorm")
+        return y
+
+    # -- tap GEMM --------------------------------------------------------------------------
+    def tapgemm(self, g: TapGemm):
+        A = _mat(g.A, "A")
+        W = _mat(g.W, "W")
+        n_out = g.N // 2 if g.epilogue == _lib.EPI_GEGLU else g.N
+        out = g.out
+        if out is None:
+            out = torch.empty((g.M, n_out), dtype=g.out_dtype, device=A.device)
+        _mat(out, "out")
+        assert out.dtype == g.out_dtype and out.shape[0] == g.M and out.shape[1] >= n_out
+        a = _lib.TapGemmArgs()
+        a.M, a.N, a.dtype = g.M, g.N, _ENUM[A.dtype]
+        a.A, a.lda, a.C1, a.taps, a.mode = A.data_ptr(), A.stride(0), g.C1, g.taps, g.mode
+        a.Hi, a.Wi, a.Ho, a.Wo = g.Hi, g.Wi, g.Ho, g.Wo
+        a.stride, a.pad_t, a.pad_l, a.ups = g.stride, g.pad_t, g.pad_l, g.ups
+        a.F, a.S = g.F, g.S
+        if g.A2 is not None:
+            A2 = _mat(g.A2, "A2")
+            assert A2.dtype == A.dtype
+            a.A2, a.lda2, a.C2 = A2.data_ptr(), A2.stride(0), g.C2
+        assert W.dtype == A.dtype and W.shape[0] >= g.N
+        a.W = W.data_ptr()
+        a.ldw = 0 if W.stride(0) == g.taps * g.C1 + g.C2 else W.stride(0)
+        if g.bias is not None:
+            assert g.bias.dtype == torch.float32 and g.bias.is_contiguous()
+            a.bias = g.bias.data_ptr()
+        if g.rowbias is not None:
+            rb = _mat(g.rowbias, "rowbias")
+            assert rb.dtype == torch.float32
+            a.rowbias, a.rowbias_ld, a.rows_per_rb = rb.data_ptr(), rb.stride(0), g.rows_per_rb
+        if g.residual is not None:
+            r = _mat(g.residual, "residual")
+            assert r.dtype == torch.float32 and r.shape[0] == g.M
+            a.residual, a.ldr = r.data_ptr(), r.stride(0)
+        a.out, a.ldo, a.out_dtype, a.epilogue = out.data_ptr(), out.stride(0), _ENUM[g.out_dtype], g.epilogue
+        prof = KERNEL_PROFILE
+        if prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        rc = self.lib.vgen_tapgemm(C.byref(a), self._stream(A))
+        if prof is not None:
+            e1.record()
+            prof.append(("tapgemm", e0, e1, 2.0 * g.M * g.N * (g.taps * g.C1 + g.C2)))
+        _lib.check(rc, "vgen_tapgemm")
+        return out
+
+    # -- attention -------------------------------------------------------------------------
+    def attention(self, g: Attn):
+        a = _lib.AttnArgs()
+        a.q, a.k, a.v, a.out = g.q.data_ptr(), g.k.data_ptr(), g.v.data_ptr(), g.out.data_ptr()
+        a.dtype, a.heads, a.nq, a.nk = _ENUM[g.q.dtype], g.heads, g.nq, g.nk
+        a.nbatch, a.inner = g.nbatch, g.inner
+        a.q_rs, a.q_bo, a.q_bi = g.q_s
+        a.k_rs, a.k_bo, a.k_bi = g.k_s
+        a.v_rs, a.v_bo, a.v_bi = g.v_s
+        a.o_rs, a.o_bo, a.o_bi = g.o_s
+        a.scale = float(g.scale)
+        rc = self.lib.vgen_attention(C.byref(a), self._stream(g.q))
+        _lib.check(rc, "vgen_attention")
+        return g.out
+
+    def softmax_rows(self, S, cols, scale, dt, out=None):
+        S = _mat(S, "S")
+        rows = S.shape[0]
+        if out is None:
+            out = torch.empty((rows, cols), dtype=dt, device=S.device)
+        _mat(out, "P")
+        rc = self.lib.vgen_softmax_rows(_ptr(S), rows, cols, S.stride(0), float(scale), _ptr(out),
+                                        out.stride(0), _ENUM[dt], self._stream(S))
+        _lib.check(rc, "vgen_softmax_rows")
+        return out
+
+    # -- small kernels -----------------------------------------------------------------------
+    def act_cast(self, x, act, dt):
+        assert x.dtype == torch.float32 and x.is_contiguous()
+        y = torch.empty(x.shape, dtype=dt, device=x.device)
+        rc = self.lib.vgen_act_cast(_ptr(x), _ptr(y), x.numel(), int(act), _ENUM[dt], self._stream(x))
+        _lib.check(rc, "vgen_act_cast")
+        return y
+
+    def timestep_embedding(self, t, dim, dt):
+        assert t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 1
+        out = torch.empty((t.shape[0], dim), dtype=dt, device=t.device)
+        rc = self.lib.vgen_timestep_embedding(_ptr(t), t.shape[0], dim, _ptr(out), _ENUM[dt],
+                                              self._stream(t))
+        _lib.check(rc, "vgen_timestep_embedding")
+        return out
+
+    def im2col3x3_small(self, src, nimg, Fi, Cin, H, W, strides, Kpad, dt):
+        assert src.dtype == torch.float32
+        out = torch.empty((nimg * H * W, Kpad), dtype=dt, device=src.device)
+        rc = self.lib.vgen_im2col3x3_small(_ptr(src), nimg, Fi, Cin, H, W, *strides, _ptr(out), Kpad,
+                                           _ENUM[dt], self._stream(src))
+        _lib.check(rc, "vgen_im2col3x3_small")
+        return out
+
+    def pointwise_small(self, src, nimg, Fi, Cin, H, W, s_strides, Wm, b, Cout, dst, d_strides):
+        assert src.dtype == torch.float32 and dst.dtype == torch.float32
+        assert Wm.dtype == torch.float32 and Wm.is_contiguous()
+        rc = self.lib.vgen_pointwise_small(_ptr(src), nimg, Fi, Cin, H, W, *s_strides, _ptr(Wm),
+                                           _ptr(b), Cout, _ptr(dst), *d_strides, self._stream(src))
+        _lib.check(rc, "vgen_pointwise_small")
+        return dst
+
+    def cfg_ddim_step(self, xt, y, u, noise, coef, guide, use_guide, mean_type, want_x0):
+        for t in (xt, y, u, noise, coef):
+            assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+        B = xt.shape[0]
+        per_b = xt.numel() // B
+        out = torch.empty_like(xt)
+        x0 = torch.empty_like(xt) if want_x0 else None
+        rc = self.lib.vgen_cfg_ddim_step(_ptr(xt), _ptr(y), _ptr(u), _ptr(noise), _ptr(coef),
+                                         float(guide), int(use_guide), int(mean_type), B, per_b,
+                                         _ptr(out), _ptr(x0), self._stream(xt))
+        _lib.check(rc, "vgen_cfg_ddim_step")
+        return out, x0
+
+    def gaussian_sample(self, moments, noise, nimg, zc, HW, scale):
+        assert moments.dtype == torch.float32 and moments.is_contiguous()
+        assert noise.dtype == torch.float32 and noise.is_contiguous()
+        z = torch.empty_like(noise)
+        rc = self.lib.vgen_gaussian_sample(_ptr(moments), _ptr(noise), nimg, zc, HW, float(scale),
+                                           _ptr(z), self._stream(moments))
+        _lib.check(rc, "vgen_gaussian_sample")
+        return z
+
+
+_backend = None
+# bench.py sets this to a list to bracket every tap-GEMM launch with HIP events on the launch
+# stream (torch's current stream) and collect (name, start, stop, algorithmic FLOP) records.
+KERNEL_PROFILE = None
+
+
+def backend():
+    global _backend
+    if _backend is None:
+        _backend = HipBackend()   # raises VgenHipError if libvgen_hip.so is missing
+    return _backend
+
+
+def set_backend(b):
+    """Test hook: install another implementation of the op set (returns the previous one)."""
+    global _backend
+    prev = _backend
+    _backend = b
+    return prev
+
+
+def sixteen(dt) -> torch.dtype:
+    if dt in (torch.bfloat16, "bf16", "bfloat16", None):
+        return torch.bfloat16
+    if dt in (torch.float16, "fp16", "f16", "float16", "half"):
+        return torch.float16
+    raise ValueError(f"compute dtype must be bf16 or fp16, got {dt}")
