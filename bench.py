@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--dump-shapes", action="store_true", help="write per-shape tap-GEMM timings to gpurun_out/")
     args = ap.parse_args()
 
     import torch.distributed as dist
@@ -194,8 +195,20 @@ def main():
         recs = ops.KERNEL_PROFILE
         ops.KERNEL_PROFILE = None
         diff.partition = part
-        ms = [a.elapsed_time(b) for _, a, b, _ in recs]
-        fl = [f for *_, f in recs]
+        ms = [r[1].elapsed_time(r[2]) for r in recs]
+        fl = [r[3] for r in recs]
+        if args.dump_shapes:
+            agg = {}
+            for r, m in zip(recs, ms):
+                a = agg.setdefault(r[4], [0, 0.0, 0.0])
+                a[0] += 1
+                a[1] += m
+                a[2] += r[3]
+            rows = sorted(([list(k), v[0], round(v[1], 4), round(v[2] / (v[1] * 1e-3) / 1e12, 1)] for k, v in agg.items()),
+                          key=lambda r: -r[2])
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "tapgemm_shapes.json"), "w") as f:
+                json.dump({"cols": ["(mode,M,N,K,epi,out)", "launches", "ms", "TFLOP/s"], "rows": rows}, f, indent=0)
         tot_ms, tot_fl = sum(ms), sum(fl)
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         res["roofline"] = {"kernel": "tapgemm_kernel", "bound": "mfma", "achieved": round(ach, 2),

@@ -1,0 +1,116 @@
+"""CPU: the oracle (oracle/torch_ref.py) is pinned (a) against the reference's own modules run
+here (marker `reference`, build container only) and (b) against the committed reference-generated
+fixtures (travels to the GPU box)."""
+import pytest
+import torch
+
+from conftest import gold, rel_l2
+from oracle import ref_import, torch_ref
+
+
+# ---- (b) fixtures ---------------------------------------------------------------------------------
+def test_oracle_unet_tiny_vs_golden():
+    g = gold("unet_tiny.pt")
+    sd = torch_ref.synth_state_dict(g["shapes"], seed=g["seed"])
+    out = torch_ref.unet_forward(sd, g["x"], g["t"], g["y"], g["cfg"]["dim"])
+    assert rel_l2(out, g["out"]) < 2e-5
+
+
+def test_oracle_vae_tiny_vs_golden():
+    g = gold("vae_tiny.pt")
+    sd = torch_ref.synth_state_dict(g["shapes"], seed=g["seed"])
+    assert rel_l2(torch_ref.vae_decode(sd, g["z"]), g["dec"]) < 2e-5
+    mom = torch_ref.vae_encode_moments(sd, g["img"])
+    assert rel_l2(mom, g["moments"]) < 2e-5
+    torch.manual_seed(g["sample_seed"])
+    noise = torch.randn(g["z_sample"].shape)
+    assert rel_l2(torch_ref.gaussian_sample(mom, noise, 0.18215), g["z_sample"]) < 2e-5
+
+
+def test_oracle_ddim_vs_golden_bit_exact():
+    from oracle.make_golden import dummy_model
+    from vgen_amd.schedules import beta_schedule
+    g = gold("ddim.pt")
+    betas = g["schedules"]["cosine_zts"]
+    out = torch_ref.ddim_sample_loop(betas, g["noise"].clone(), dummy_model, g["kw"], 9.0, 50, "v", 0.0)
+    assert torch.equal(out, g["out50"])
+    tabs = torch_ref.ddim_tables(betas)
+    assert torch.equal(tabs["ac"], g["tables"]["alphas_cumprod"])
+    assert torch.equal(tabs["sqrt_recipm1"], g["tables"]["sqrt_recipm1"])
+    # timestep list of the 50-step DDIM run: 981, 961, ..., 21, 1
+    ts = torch_ref.ddim_timesteps(1000, 50)
+    assert ts[0] == 981 and ts[-1] == 1 and len(ts) == 50 and int(ts[1]) == 961
+
+
+def test_synth_weights_are_nondegenerate_and_reproducible():
+    g = gold("unet_tiny.pt")
+    a = torch_ref.synth_state_dict(g["shapes"], seed=1)
+    b = torch_ref.synth_state_dict(g["shapes"], seed=1)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    # the layers the reference zero-initialises must be non-zero (SURVEY §8c trap)
+    for k in ("out.2.weight", "middle_block.0.out_layers.3.weight", "middle_block.1.proj_out.weight",
+              "middle_block.0.temopral_conv.conv4.3.weight"):
+        assert a[k].abs().max() > 0
+
+
+# ---- (a) live reference ---------------------------------------------------------------------------
+@pytest.mark.reference
+def test_oracle_unet_vs_live_reference():
+    from oracle.make_golden import UNET_TINY
+    R = ref_import.load()
+    ref = R["MODEL"].build(dict(type="UNetSD_T2VBase", **UNET_TINY)).eval()
+    sd = torch_ref.synth_state_dict(torch_ref.shapes_of(ref), seed=7)
+    ref.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1, 4, 3, 8, 8, generator=g)        # odd frame count, other resolution
+    y = torch.randn(1, 5, 1024, generator=g)           # short context
+    t = torch.tensor([37])
+    with torch.no_grad():
+        assert rel_l2(torch_ref.unet_forward(sd, x, t, y, UNET_TINY["dim"]), ref(x, t, y=y)) < 2e-5
+
+
+@pytest.mark.reference
+def test_oracle_blocks_vs_live_reference():
+    R = ref_import.load()
+    U = R["util"]
+    g = torch.Generator().manual_seed(0)
+
+    def synth(m, seed):
+        sd = torch_ref.synth_state_dict(torch_ref.shapes_of(m), seed=seed)
+        m.load_state_dict(sd, strict=True)
+        return sd
+
+    with torch.no_grad():
+        rb = U.ResBlock(128, 256, 0.1, out_channels=64, use_scale_shift_norm=False).eval()
+        sd = synth(rb, 1)
+        x, e = torch.randn(6, 128, 5, 7, generator=g), torch.randn(6, 256, generator=g)
+        assert rel_l2(torch_ref.resblock({"rb." + k: v for k, v in sd.items()}, "rb", x, e, 2), rb(x, e, 2)) < 2e-5
+        st = U.SpatialTransformer(128, 2, 64, depth=1, context_dim=96, use_linear=True).eval()
+        sd = synth(st, 2)
+        x, c = torch.randn(3, 128, 4, 5, generator=g), torch.randn(3, 9, 96, generator=g)
+        assert rel_l2(torch_ref.spatial_transformer({"m." + k: v for k, v in sd.items()}, "m", x, c), st(x, c)) < 2e-5
+        tt = U.TemporalTransformer(64, 2, 64, depth=1, context_dim=96).eval()      # inner 128 != 64
+        sd = synth(tt, 3)
+        x = torch.randn(2, 64, 6, 3, 4, generator=g)
+        assert rel_l2(torch_ref.temporal_transformer({"m." + k: v for k, v in sd.items()}, "m", x), tt(x)) < 2e-5
+
+
+@pytest.mark.reference
+def test_oracle_vae_and_sampler_vs_live_reference():
+    from oracle.make_golden import DDIM_T2V, VAE_TINY, dummy_model
+    R = ref_import.load()
+    vae = R["AUTO_ENCODER"].build(dict(type="AutoencoderKL", ddconfig=VAE_TINY, embed_dim=4)).eval()
+    sd = torch_ref.synth_state_dict(torch_ref.shapes_of(vae), seed=4)
+    vae.load_state_dict(sd, strict=True)
+    g = torch.Generator().manual_seed(1)
+    with torch.no_grad():
+        z = torch.randn(1, 4, 6, 10, generator=g)
+        assert rel_l2(torch_ref.vae_decode(sd, z), vae.decode(z)) < 2e-5
+        img = torch.randn(1, 3, 48, 80, generator=g)
+        assert rel_l2(torch_ref.vae_encode_moments(sd, img), vae.encode(img).parameters) < 2e-5
+    diff = R["DIFFUSION"].build(dict(type="DiffusionDDIM", **DDIM_T2V))
+    noise = torch.randn(1, 4, 2, 4, 4, generator=g)
+    kw = [dict(y=torch.randn(1, 3, 8, generator=g)), dict(y=torch.randn(1, 3, 8, generator=g))]
+    a = diff.ddim_sample_loop(noise.clone(), dummy_model, kw, guide_scale=7.5, ddim_timesteps=25, eta=0.0)
+    b = torch_ref.ddim_sample_loop(diff.betas, noise.clone(), dummy_model, kw, 7.5, 25, "v", 0.0)
+    assert torch.equal(a, b)

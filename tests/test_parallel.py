@@ -1,0 +1,90 @@
+"""Multi-GPU path on CPU: world_size-2 gloo processes run the unit partition + single all-gather
+per step and must reproduce the single-process sampler exactly."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class _ToyUNet(torch.nn.Module):
+    out_dim = 4
+
+    def forward(self, x, t, y=None, **kw):
+        w = torch.tensor([[0.6, -0.2, 0.1, 0.0], [0.1, 0.5, -0.3, 0.2], [-0.2, 0.1, 0.7, 0.1], [0.0, 0.3, -0.1, 0.4]])
+        o = torch.einsum("oc,bcfhw->bofhw", w, x.float())
+        return o + 0.05 * y.float().mean(dim=(1, 2)).view(-1, 1, 1, 1, 1) + 0.001 * t.float().view(-1, 1, 1, 1, 1)
+
+
+def _worker(rank, world, port, P, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.abi_emulator import EmuBackend
+    from vgen_amd import ops
+    from vgen_amd.diffusion import DiffusionDDIM
+    from vgen_amd.parallel import UnitPartition
+    ops.set_backend(EmuBackend())
+    g = torch.Generator().manual_seed(0)
+    noise = torch.randn(P, 4, 2, 4, 4, generator=g)
+    kw = [dict(y=torch.randn(P, 7, 8, generator=g)), dict(y=torch.randn(P, 7, 8, generator=g))]
+    d = DiffusionDDIM(schedule="cosine", schedule_param=dict(num_timesteps=1000, cosine_s=0.008, zero_terminal_snr=True),
+                      mean_type="v", var_type="fixed_small")
+    d.partition = UnitPartition()
+    assert d.partition.world == world and d.partition.rank == rank
+    out = d.ddim_sample_loop(noise.clone(), _ToyUNet(), kw, guide_scale=9.0, ddim_timesteps=10, eta=0.0)
+    q.put((rank, out, d.partition.my_units(2 * P)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("P", [1, 3])
+def test_unit_partition_world2_matches_single_process(P):
+    from oracle.abi_emulator import EmuBackend
+    from vgen_amd import ops
+    from vgen_amd.diffusion import DiffusionDDIM
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, P, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    prev = ops.set_backend(EmuBackend())
+    try:
+        g = torch.Generator().manual_seed(0)
+        noise = torch.randn(P, 4, 2, 4, 4, generator=g)
+        kw = [dict(y=torch.randn(P, 7, 8, generator=g)), dict(y=torch.randn(P, 7, 8, generator=g))]
+        d = DiffusionDDIM(schedule="cosine", schedule_param=dict(num_timesteps=1000, cosine_s=0.008, zero_terminal_snr=True),
+                          mean_type="v", var_type="fixed_small")
+        ref = d.ddim_sample_loop(noise.clone(), _ToyUNet(), kw, guide_scale=9.0, ddim_timesteps=10, eta=0.0)
+    finally:
+        ops.set_backend(prev)
+    assert torch.equal(res[0][1], res[1][1])                    # all ranks hold the same state
+    assert torch.allclose(res[0][1], ref, atol=1e-6, rtol=1e-6)
+    units = sorted(res[0][2] + res[1][2])
+    assert units == list(range(2 * P))                           # every unit owned exactly once
+    assert all(u % 2 == 0 for u in res[0][2]) and all(u % 2 == 1 for u in res[1][2])
+
+
+def test_partition_single_process_is_identity():
+    from vgen_amd.parallel import UnitPartition
+    p = UnitPartition()
+    assert p.world == 1 and p.my_units(4) == [0, 1, 2, 3] and p.slots(4) == 4
+    outs = [torch.full((2, 3), float(i)) for i in range(4)]
+    got = p.gather_units(outs, 4, outs[0])
+    assert all(torch.equal(a, b) for a, b in zip(got, outs))

@@ -165,7 +165,8 @@ class HipBackend:
         rc = self.lib.vgen_tapgemm(C.byref(a), self._stream(A))
         if prof is not None:
             e1.record()
-            prof.append(("tapgemm", e0, e1, 2.0 * g.M * g.N * (g.taps * g.C1 + g.C2)))
+            prof.append(("tapgemm", e0, e1, 2.0 * g.M * g.N * (g.taps * g.C1 + g.C2),
+                         (g.mode, g.M, g.N, g.taps * g.C1 + g.C2, g.epilogue, str(g.out_dtype))))
         _lib.check(rc, "vgen_tapgemm")
         return out
 
