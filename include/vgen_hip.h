@@ -142,8 +142,15 @@ typedef struct vgen_tapgemm_args {
   int64_t ldo;
   int32_t out_dtype;
   int32_t epilogue;
+  void* ws;        /* optional split-K workspace (fp32), see vgen_tapgemm_ws_bytes */
+  size_t ws_bytes;
 } vgen_tapgemm_args;
 
+/* Launches whose tile count cannot fill the 256 CUs (small M: the 4x7 / 8x14 UNet levels) are
+ * split along K; the partial fp32 tiles need `vgen_tapgemm_ws_bytes(args)` bytes of caller
+ * scratch (0 = no split for this shape).  Without a large enough `ws` the call still succeeds
+ * unsplit.  The reduction order is fixed, so results are deterministic. */
+size_t vgen_tapgemm_ws_bytes(const vgen_tapgemm_args* args);
 int vgen_tapgemm(const vgen_tapgemm_args* args, void* stream);
 
 /* ------------------------------------------------------------------------------------

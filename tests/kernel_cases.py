@@ -281,6 +281,11 @@ def tapgemm_cases(dt):
                                      Wo=6, stride=1, pad_t=1, pad_l=1, ups=0, C2=192)
     c["conv_big"] = make_tapgemm(dt, 4 * 32 * 56, 320, 320, mode=L.TAP_CONV3X3, nimg=4, Hi=32, Wi=56,
                                  Ho=32, Wo=56, stride=1, pad_t=1, pad_l=1, ups=0, residual=True)
+    c["conv_splitk_L3"] = make_tapgemm(dt, 16 * 4 * 7, 1280, 1280, mode=L.TAP_CONV3X3, nimg=16, Hi=4, Wi=7,
+                                       Ho=4, Wo=7, stride=1, pad_t=1, pad_l=1, ups=0, residual=True, rowbias=28 * 8)
+    c["lin_splitk_geglu"] = make_tapgemm(dt, 100, 512, 1024, epilogue=L.EPI_GEGLU, out_dtype=dt, residual=True)
+    c["lin_splitk_out16"] = make_tapgemm(dt, 300, 256, 2048, out_dtype=dt)
+    c["temporal_splitk"] = make_tapgemm(dt, 2 * 4 * 28, 640, 640, mode=L.TAP_TEMPORAL3, F=4, S=28, residual=True)
     c["temporal"] = make_tapgemm(dt, 2 * 5 * 24, 64, 64, mode=L.TAP_TEMPORAL3, F=5, S=24, residual=True)
     c["temporal_b128"] = make_tapgemm(dt, 1 * 16 * 28, 128, 128, mode=L.TAP_TEMPORAL3, F=16, S=28)
     return c

@@ -13,12 +13,18 @@
 //   * operands swapped on the matrix core: D[i = n][j = m] = sum_k W[n,k] * A[m,k].  The
 //     C/D fragment then holds 4 CONSECUTIVE n for one m per lane -> bias / residual / output
 //     move as one 16-byte (fp32) or 8-byte (16-bit) vector per fragment.
-//   * global -> VGPR -> LDS staging, double-buffered, one barrier per K-tile: the loads of
-//     tile t+1 are issued before the MFMAs of tile t and written to the other LDS buffer
-//     after them (issue-early / write-late).
-//   * LDS tiles are [rows][64] 16-bit (128 B / row) with the 16-byte chunk index XOR-swizzled
-//     by (row & 7): ds_write_b128 of a row's 8 chunks and ds_read_b128 of a fragment
-//     (16 rows x one chunk per 16-lane group) are both bank-conflict free.
+//   * global -> LDS staging by LDS-DMA (`global_load_lds_dwordx4`, 1 KiB = 8 tile rows per
+//     wave-instruction): no staging VGPRs and no ds_write pass (the v1 register-staged kernel was
+//     LDS-write bound: 32 KiB of ds_write_b128 per K-tile at ~79 B/clk/CU).  Double-buffered,
+//     one barrier per K-tile: the DMA of tile t+1 is issued before the MFMAs of tile t.
+//     Out-of-range rows (conv padding, M/N tails) read a 16-byte zero line instead.
+//   * LDS tiles are [rows][64] 16-bit (128 B / row).  The DMA destination is lane-linear, so the
+//     XOR swizzle (chunk ^ (row & 7)) is applied on the per-lane SOURCE address and again on the
+//     fragment reads: ds_read_b128 of a fragment (16 rows x one chunk per 16-lane group) is
+//     bank-conflict free.
+//   * split-K for launches with too few tiles to fill 256 CUs (the 4x7 / 8x14 levels of the UNet:
+//     M = 896): partial fp32 tiles go to a caller workspace and a small second kernel reduces them
+//     in a fixed order (deterministic) and applies the epilogue.
 //   * fp32 accumulate; epilogue in fp32: + bias + per-image row-bias (time embedding)
 //     + fp32 residual, optional GEGLU gate, fp32 or 16-bit store.
 #include "common.h"
@@ -36,8 +42,19 @@ struct RowState {
 
 constexpr int INVALID = -(1 << 24);
 
+__device__ u32x4 g_zero16 = {0u, 0u, 0u, 0u};   // source of padding / out-of-range rows
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_base) {
+  // 64 lanes x 16 B -> LDS [lds_wave_base + lane*16]; the LDS base must be wave-uniform
+  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
 template <typename T, int BM, int BN>
-__global__ __launch_bounds__(256) void tapgemm_kernel(const vgen_tapgemm_args p) {
+__global__ __launch_bounds__(256) void tapgemm_kernel(const vgen_tapgemm_args p, const int splitk,
+                                                      float* __restrict__ ws) {
   constexpr int WN = BN / 64;
   constexpr int WM = 4 / WN;
   static_assert(WM * 64 == BM, "block tile must be 4 waves of 64x64");
@@ -101,18 +118,25 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const vgen_tapgemm_args p)
   const int cpt1 = p.C1 / BK;           // K-tiles per tap of segment 1
   const int T1 = p.taps * cpt1;
   const int KT = T1 + p.C2 / BK;
-
-  u32x4 ra[RA];
-  u32x4 rb[RB];
+  // this block's K-tile range (split-K: blockIdx.y)
+  const int split = blockIdx.y;
+  const int kt_begin = (int)(((int64_t)KT * split) / splitk);
+  const int kt_end = (int)(((int64_t)KT * (split + 1)) / splitk);
 
   // running (tap, c0) of the NEXT tile to load
-  int nx_tap = 0, nx_c = 0;
+  int nx_tap = kt_begin / cpt1, nx_c = kt_begin - (kt_begin / cpt1) * cpt1;
 
-  auto load_tile = [&](int kt) {
+  // source chunk of this lane: LDS position ld_c holds chunk ld_c ^ (row & 7)
+  const int src_c = (ld_c ^ (ld_r & 7)) * 8;
+  const int wave_row0 = (tid >> 6) * 8;    // first tile row written by this wave's DMA (+32*i)
+
+  auto load_tile = [&](int kt, int buf) {
+    unsigned char* const dA = sA + buf * BM * ROW_BYTES + wave_row0 * ROW_BYTES;
+    unsigned char* const dB = sB + buf * BN * ROW_BYTES + wave_row0 * ROW_BYTES;
     // ---- A rows ----
     if (kt < T1) {
       const int tap = nx_tap;
-      const int c0 = nx_c * BK + ld_c * 8;
+      const int c0 = nx_c * BK + src_c;
       int d0 = 0, d1 = 0;
       if (p.mode == VGEN_TAP_CONV3X3) {
         d0 = tap / 3;
@@ -136,42 +160,31 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const vgen_tapgemm_args p)
           ok = rs[i].base >= 0;
           row = rs[i].base;
         }
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (ok) v = *(const u32x4*)(A + row * p.lda + c0);
-        ra[i] = v;
+        const void* src = ok ? (const void*)(A + row * p.lda + c0) : (const void*)&g_zero16;
+        glds16(src, dA + i * 32 * ROW_BYTES);
       }
       if (++nx_c == cpt1) {
         nx_c = 0;
         ++nx_tap;
       }
     } else {
-      const int c0 = (kt - T1) * BK + ld_c * 8;
+      const int c0 = (kt - T1) * BK + src_c;
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if ((mvalid >> i) & 1u) v = *(const u32x4*)(A2 + (m0 + ld_r + 32 * i) * p.lda2 + c0);
-        ra[i] = v;
+        const void* src = ((mvalid >> i) & 1u)
+                              ? (const void*)(A2 + (m0 + ld_r + 32 * i) * p.lda2 + c0)
+                              : (const void*)&g_zero16;
+        glds16(src, dA + i * 32 * ROW_BYTES);
       }
     }
     // ---- W rows ----
-    const int64_t kofs = (int64_t)kt * BK + ld_c * 8;
+    const int64_t kofs = (int64_t)kt * BK + src_c;
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
       const int n = n0 + ld_r + 32 * i;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (n < p.N) v = *(const u32x4*)(W + (int64_t)n * ldw + kofs);
-      rb[i] = v;
+      const void* src = n < p.N ? (const void*)(W + (int64_t)n * ldw + kofs) : (const void*)&g_zero16;
+      glds16(src, dB + i * 32 * ROW_BYTES);
     }
-  };
-
-  const int st_off = ld_r * ROW_BYTES + ((ld_c ^ (ld_r & 7)) << 4);  // (row+32i)&7 == row&7
-  auto store_tile = [&](int buf) {
-    unsigned char* a = sA + buf * BM * ROW_BYTES + st_off;
-    unsigned char* b = sB + buf * BN * ROW_BYTES + st_off;
-#pragma unroll
-    for (int i = 0; i < RA; ++i) *(u32x4*)(a + i * 32 * ROW_BYTES) = ra[i];
-#pragma unroll
-    for (int i = 0; i < RB; ++i) *(u32x4*)(b + i * 32 * ROW_BYTES) = rb[i];
   };
 
   f32x4 acc[4][4];
@@ -203,15 +216,32 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const vgen_tapgemm_args p)
   };
 
   // ---- main loop: one barrier per K-tile ------------------------------------------------
-  load_tile(0);
-  store_tile(0);
+  // The DMA is tracked by vmcnt; the explicit wait + barrier publishes a landed tile to all waves
+  // and (WAR) guarantees every wave finished reading the buffer the next DMA overwrites.
+  load_tile(kt_begin, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  for (int kt = 0; kt < KT; ++kt) {
-    const bool more = kt + 1 < KT;
-    if (more) load_tile(kt + 1);
-    compute(kt & 1);
-    if (more) store_tile((kt + 1) & 1);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int buf = (kt - kt_begin) & 1;
+    if (kt + 1 < kt_end) load_tile(kt + 1, buf ^ 1);
+    compute(buf);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  }
+
+  if (splitk > 1) {   // raw fp32 partial tile -> workspace [split][M][N]; epilogue in the reducer
+    float* const wsp = ws + (int64_t)split * p.M * p.N;
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi) {
+      const int64_t m = m0 + wm * 64 + mi * 16 + lr;
+      if (m >= p.M) continue;
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        const int n = n0 + wn * 64 + ni * 16 + lq * 4;
+        if (n < p.N) *(f32x4*)(wsp + m * p.N + n) = acc[ni][mi];
+      }
+    }
+    return;
   }
 
   // ---- epilogue -------------------------------------------------------------------------
@@ -283,6 +313,57 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const vgen_tapgemm_args p)
   }
 }
 
+// split-K reducer: fixed summation order over the splits, then the same epilogue as the main kernel
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const vgen_tapgemm_args p, const int splitk,
+                                                            const float* __restrict__ ws) {
+  const bool geglu = p.epilogue == VGEN_EPI_GEGLU;
+  const int n_out = geglu ? p.N / 2 : p.N;
+  const int ng = n_out >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.M * ng) return;
+  const int64_t m = idx / ng;
+  const int j = (int)(idx - m * ng) * 4;
+  const int64_t plane = p.M * (int64_t)p.N;
+  const int pn = geglu ? 32 * (j >> 4) + (j & 15) : j;
+  f32x4 v = {0, 0, 0, 0}, gt = {0, 0, 0, 0};
+  for (int s = 0; s < splitk; ++s) {
+    v += *(const f32x4*)(ws + s * plane + m * p.N + pn);
+    if (geglu) gt += *(const f32x4*)(ws + s * plane + m * p.N + pn + 16);
+  }
+  if (p.bias) {
+    v += *(const f32x4*)(p.bias + pn);
+    if (geglu) gt += *(const f32x4*)(p.bias + pn + 16);
+  }
+  if (geglu) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = v[r] * gelu_erf_f(gt[r]);
+  } else if (p.rowbias) {
+    v += *(const f32x4*)(p.rowbias + (m / p.rows_per_rb) * p.rowbias_ld + j);
+  }
+  if (p.residual) v += *(const f32x4*)(p.residual + m * p.ldr + j);
+  if (p.out_dtype == VGEN_F32) *(f32x4*)((float*)p.out + m * p.ldo + j) = v;
+  else *(u32x2*)((uint16_t*)p.out + m * p.ldo + j) = pack4<T>(v.x, v.y, v.z, v.w);
+}
+
+// Deterministic split-K plan: only for launches that cannot fill the chip and whose epilogue
+// operands are 16-byte vectorisable.
+int plan_splitk(const vgen_tapgemm_args& a) {
+  const bool wide = (a.N % 128 == 0);
+  const int BM = wide ? 128 : 256, BN = wide ? 128 : 64;
+  const int64_t tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+  const int KT = a.taps * (a.C1 / 64) + a.C2 / 64;
+  const int n_out = a.epilogue == VGEN_EPI_GEGLU ? a.N / 2 : a.N;
+  const bool vec = (a.N % 4 == 0) && (n_out % 4 == 0) && (a.ldo % 4 == 0) &&
+                   (a.residual == nullptr || a.ldr % 4 == 0) &&
+                   (a.rowbias == nullptr || a.rowbias_ld % 4 == 0);
+  if (!vec || tiles >= 160 || KT < 16) return 1;
+  int64_t s = (384 + tiles - 1) / tiles;
+  if (s > KT / 8) s = KT / 8;
+  if (s > 32) s = 32;
+  return s < 2 ? 1 : (int)s;
+}
+
 template <typename T, int BM, int BN>
 int launch(const vgen_tapgemm_args& a, hipStream_t stream) {
   constexpr size_t lds = 2 * (size_t)(BM + BN) * ROW_BYTES;
@@ -305,11 +386,27 @@ int launch(const vgen_tapgemm_args& a, hipStream_t stream) {
     vgen_set_error("tapgemm: grid too large");
     return VGEN_E_BADARG;
   }
-  hipLaunchKernelGGL((tapgemm_kernel<T, BM, BN>), dim3((unsigned)grid), dim3(256), lds, stream, a);
-  return vgen_check_launch("tapgemm");
+  int splitk = plan_splitk(a);
+  if (splitk > 1 && (a.ws == nullptr || a.ws_bytes < (size_t)splitk * a.M * a.N * sizeof(float)))
+    splitk = 1;   // caller did not provide the workspace: still correct, just fewer blocks
+  hipLaunchKernelGGL((tapgemm_kernel<T, BM, BN>), dim3((unsigned)grid, (unsigned)splitk), dim3(256), lds,
+                     stream, a, splitk, (float*)a.ws);
+  int rc = vgen_check_launch("tapgemm");
+  if (rc || splitk == 1) return rc;
+  const int n_out = a.epilogue == VGEN_EPI_GEGLU ? a.N / 2 : a.N;
+  const int64_t threads = a.M * (n_out / 4);
+  hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                     stream, a, splitk, (const float*)a.ws);
+  return vgen_check_launch("tapgemm(splitk reduce)");
 }
 
 }  // namespace
+
+extern "C" size_t vgen_tapgemm_ws_bytes(const vgen_tapgemm_args* args) {
+  if (!args || args->N <= 0 || args->M <= 0 || args->C1 <= 0 || args->C1 % 64 || args->C2 % 64) return 0;
+  const int s = plan_splitk(*args);
+  return s > 1 ? (size_t)s * args->M * args->N * sizeof(float) : 0;
+}
 
 extern "C" int vgen_tapgemm(const vgen_tapgemm_args* args, void* stream) {
   if (!args) {
@@ -332,6 +429,7 @@ extern "C" int vgen_tapgemm(const vgen_tapgemm_args* args, void* stream) {
   VGEN_REQUIRE(a.rowbias == nullptr || (vgen_aligned16(a.rowbias) && a.rows_per_rb > 0),
                "tapgemm: rowbias alignment / rows_per_rb");
   VGEN_REQUIRE(a.out_dtype == VGEN_F32 || a.out_dtype == a.dtype, "tapgemm: out_dtype");
+  VGEN_REQUIRE(a.ws == nullptr || vgen_aligned16(a.ws), "tapgemm: workspace alignment");
   switch (a.mode) {
     case VGEN_TAP_LINEAR:
       VGEN_REQUIRE(a.taps == 1, "tapgemm: linear mode needs taps == 1");

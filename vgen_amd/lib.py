@@ -36,6 +36,7 @@ class TapGemmArgs(C.Structure):
         ("rows_per_rb", C.c_int64), ("residual", C.c_void_p), ("ldr", C.c_int64),
         ("out", C.c_void_p), ("ldo", C.c_int64), ("out_dtype", C.c_int32),
         ("epilogue", C.c_int32),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
     ]
 
 
@@ -61,6 +62,7 @@ SYMBOLS = {
     "vgen_groupnorm": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i64, _i32, _f32, _vp, _vp, _i32,
                                  _vp, _vp, _i32, _vp, _sz, _vp]),
     "vgen_layernorm": (C.c_int, [_vp, _i64, _i32, _f32, _vp, _vp, _vp, _i32, _vp]),
+    "vgen_tapgemm_ws_bytes": (_sz, [C.POINTER(TapGemmArgs)]),
     "vgen_tapgemm": (C.c_int, [C.POINTER(TapGemmArgs), _vp]),
     "vgen_attention": (C.c_int, [C.POINTER(AttnArgs), _vp]),
     "vgen_softmax_rows": (C.c_int, [_vp, _i64, _i32, _i64, _f32, _vp, _i64, _i32, _vp]),

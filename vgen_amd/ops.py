@@ -158,6 +158,10 @@ class HipBackend:
             assert r.dtype == torch.float32 and r.shape[0] == g.M
             a.residual, a.ldr = r.data_ptr(), r.stride(0)
         a.out, a.ldo, a.out_dtype, a.epilogue = out.data_ptr(), out.stride(0), _ENUM[g.out_dtype], g.epilogue
+        need = self.lib.vgen_tapgemm_ws_bytes(C.byref(a))
+        if need:
+            ws = torch.empty(need // 4, dtype=torch.float32, device=A.device)
+            a.ws, a.ws_bytes = ws.data_ptr(), need
         prof = KERNEL_PROFILE
         if prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
