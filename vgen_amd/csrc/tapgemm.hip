@@ -6,33 +6,44 @@
 //     channels-last row layout every tap's K-slab is one contiguous C-length row of a shifted
 //     pixel / frame, so a conv A-tile is a row GATHER of 128-byte pieces — no im2col buffer,
 //     no torch.cat, no F.interpolate, no rearrange.
-//   * 256 threads = 4 waves; block tile BM x BN with BK = 64; each wave owns a 64(m) x 64(n)
-//     sub-tile = 4x4 MFMA 16x16x32 fragments (64 fp32 accumulators / lane).
-//     Two shapes: 128x128 (2x2 waves) for N % 128 == 0, 256x64 (4x1 waves) otherwise
-//     (N = 320/960: 5 / 15 exact 64-wide tiles instead of 2.5 / 7.5 128-wide ones).
+//   * 512 threads = 8 waves (4 along M x 2 along N), ONE block per CU.  Block tile 256 x BN with
+//     BK = 64; BN = 128 (N % 128 == 0), 160 (N = 320 / 960 ...: exact tiles instead of 2.5 x 128)
+//     or 64 (small / odd N).  Each wave owns a 64 x (BN/2) sub-tile of 16x16x32 MFMA fragments.
+//     256-row tiles halve the L2->LDS bytes per flop of a 128x128 tile (85-98 flop/B).
 //   * operands swapped on the matrix core: D[i = n][j = m] = sum_k W[n,k] * A[m,k].  The
 //     C/D fragment then holds 4 CONSECUTIVE n for one m per lane -> bias / residual / output
 //     move as one 16-byte (fp32) or 8-byte (16-bit) vector per fragment.
 //   * global -> LDS staging by LDS-DMA (`global_load_lds_dwordx4`, 1 KiB = 8 tile rows per
-//     wave-instruction): no staging VGPRs and no ds_write pass (the v1 register-staged kernel was
-//     LDS-write bound: 32 KiB of ds_write_b128 per K-tile at ~79 B/clk/CU).  Double-buffered,
-//     one barrier per K-tile: the DMA of tile t+1 is issued before the MFMAs of tile t.
+//     wave-instruction): no staging VGPRs, no ds_write pass.  THREE-stage ring (up to 156 KiB of
+//     the 160 KiB LDS), one raw s_barrier per K-tile, COUNTED vmcnt: while tile t is multiplied
+//     the DMAs of tiles t+1 and t+2 stay in flight across the barrier (~100 KiB in flight per CU,
+//     what Little's law asks for at ~1 us of loaded L2/MALL latency).  v1 (register staging,
+//     2 stages) was LDS-write bound, v2 (DMA, 2 stages, vmcnt(0) + __syncthreads) spent 40-50 %
+//     of its wave cycles parked at the wait (profiles/).
 //     Out-of-range rows (conv padding, M/N tails) read a 16-byte zero line instead.
 //   * LDS tiles are [rows][64] 16-bit (128 B / row).  The DMA destination is lane-linear, so the
 //     XOR swizzle (chunk ^ (row & 7)) is applied on the per-lane SOURCE address and again on the
 //     fragment reads: ds_read_b128 of a fragment (16 rows x one chunk per 16-lane group) is
-//     bank-conflict free.
-//   * split-K for launches with too few tiles to fill 256 CUs (the 4x7 / 8x14 levels of the UNet:
-//     M = 896): partial fp32 tiles go to a caller workspace and a small second kernel reduces them
-//     in a fixed order (deterministic) and applies the epilogue.
+//     bank-conflict free (SQ_LDS_BANK_CONFLICT = 0 measured).
+//   * XCD-aware tile order: block b runs on XCD b % 8; tiles are renumbered so that each XCD works
+//     on a contiguous run of tiles (same A rows, consecutive W panels) -> its private L2 sees reuse.
+//   * split-K for launches with too few tiles to fill 256 CUs (the 4x7 / 8x14 levels of the UNet):
+//     partial fp32 tiles go to a caller workspace and a small second kernel reduces them in a
+//     fixed order (deterministic) and applies the epilogue.
 //   * fp32 accumulate; epilogue in fp32: + bias + per-image row-bias (time embedding)
 //     + fp32 residual, optional GEGLU gate, fp32 or 16-bit store.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int BK = 64;          // K elements per tile (128 bytes per row)
 constexpr int ROW_BYTES = 128;  // BK * 2
+constexpr int STAGES = 3;
+constexpr int BM = 256;
+constexpr int WM = 4, WN = 2;   // wave grid
+constexpr int NT = WM * WN * 64;
+constexpr int RPP = NT / 8;     // tile rows covered by one DMA pass of the whole block (64)
 
 struct RowState {
   int base;  // LINEAR/TEMPORAL: source row m; CONV: img * Hi * Wi
@@ -52,29 +63,41 @@ __device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_
   __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
-template <typename T, int BM, int BN>
-__global__ __launch_bounds__(256) void tapgemm_kernel(const vgen_tapgemm_args p, const int splitk,
-                                                      float* __restrict__ ws) {
-  constexpr int WN = BN / 64;
-  constexpr int WM = 4 / WN;
-  static_assert(WM * 64 == BM, "block tile must be 4 waves of 64x64");
-  constexpr int RA = BM / 32;  // A rows staged per thread
-  constexpr int RB = BN / 32;  // W rows staged per thread
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <typename T, int BN>
+__global__ __launch_bounds__(NT) void tapgemm_kernel(const vgen_tapgemm_args p, const int splitk,
+                                                     float* __restrict__ ws) {
+  constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile 64 x {64, 80, 32}
+  constexpr int MF = WTM / 16, NF = WTN / 16;   // fragments per wave
+  constexpr int RA = BM / RPP;                  // A DMA passes per tile (4)
+  constexpr int RBF = BN / RPP;                 // full W passes
+  constexpr int RBT = BN % RPP;                 // tail rows of W: only waves with wave*8 < RBT issue
+  constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
+  constexpr int LPT = RA + RBF;                 // DMA instructions per wave per tile (+1 with tail)
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  unsigned char* const sA = smem;                          // [2][BM][128 B]
-  unsigned char* const sB = smem + 2 * BM * ROW_BYTES;     // [2][BN][128 B]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN;
   const int wn = wave % WN;
   const int lr = lane & 15;  // row within a 16-row fragment
   const int lq = lane >> 4;  // 16-lane group: k-chunk (operands) / 4-row group (C/D)
+  const bool w_tail = RBT > 0 && wave * 8 < RBT;
 
+  // ---- XCD-aware tile renumbering (bijective for any grid size) ----------------------------
   const int tiles_n = (p.N + BN - 1) / BN;
-  const int64_t tile = blockIdx.x;
+  int64_t tile;
+  {
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned xcd = bid & 7u, q = nwg >> 3, r = nwg & 7u;
+    tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
   const int64_t m0 = (tile / tiles_n) * BM;
   const int n0 = (int)(tile % tiles_n) * BN;
 
@@ -83,7 +106,7 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const vgen_tapgemm_args p,
   const uint16_t* __restrict__ W = (const uint16_t*)p.W;
   const int64_t ldw = p.ldw ? p.ldw : (int64_t)p.taps * p.C1 + p.C2;
 
-  // ---- per-thread staging assignment: chunk (16 B) ld_c of rows ld_r + 32*i ------------
+  // ---- per-thread DMA assignment: LDS chunk position ld_c of tile rows ld_r + 64*i -----------
   const int ld_c = tid & 7;
   const int ld_r = tid >> 3;
 
@@ -91,22 +114,23 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const vgen_tapgemm_args p,
   unsigned mvalid = 0;
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
-    const int64_t m = m0 + ld_r + 32 * i;
-    const bool ok = m < p.M;
+    // M < 2^31 is enforced by the host wrapper: 32-bit index math (64-bit divides cost ~1 us/block)
+    const unsigned m = (unsigned)m0 + ld_r + RPP * i;
+    const bool ok = m < (unsigned)p.M;
     if (ok) mvalid |= 1u << i;
     if (p.mode == VGEN_TAP_CONV3X3) {
-      const int hw = p.Ho * p.Wo;
-      const int img = (int)(m / hw);
-      const int rem = (int)(m - (int64_t)img * hw);
-      const int oy = rem / p.Wo;
-      const int ox = rem - oy * p.Wo;
+      const unsigned hw = p.Ho * p.Wo;
+      const unsigned img = m / hw;
+      const unsigned rem = m - img * hw;
+      const unsigned oy = rem / (unsigned)p.Wo;
+      const unsigned ox = rem - oy * p.Wo;
       rs[i].base = img * p.Hi * p.Wi;
-      rs[i].a = ok ? oy * p.stride - p.pad_t : INVALID;
-      rs[i].b = ox * p.stride - p.pad_l;
+      rs[i].a = ok ? (int)oy * p.stride - p.pad_t : INVALID;
+      rs[i].b = (int)ox * p.stride - p.pad_l;
     } else if (p.mode == VGEN_TAP_TEMPORAL3) {
-      const int64_t fs = m / p.S;  // global frame index b*F + f
+      const unsigned fs = m / (unsigned)p.S;  // global frame index b*F + f
       rs[i].base = (int)m;
-      rs[i].a = ok ? (int)(fs % p.F) : INVALID;
+      rs[i].a = ok ? (int)(fs % (unsigned)p.F) : INVALID;
       rs[i].b = 0;
     } else {
       rs[i].base = ok ? (int)m : -1;
@@ -122,21 +146,28 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const vgen_tapgemm_args p,
   const int split = blockIdx.y;
   const int kt_begin = (int)(((int64_t)KT * split) / splitk);
   const int kt_end = (int)(((int64_t)KT * (split + 1)) / splitk);
+  const int nk = kt_end - kt_begin;
 
-  // running (tap, c0) of the NEXT tile to load
-  int nx_tap = kt_begin / cpt1, nx_c = kt_begin - (kt_begin / cpt1) * cpt1;
+  // ---- incremental per-lane DMA source pointers ---------------------------------------------
+  // pc[j] = source of piece j for the NEXT K-tile to issue; consecutive K-tiles inside one tap /
+  // K segment just advance by 128 bytes (0 for rows that read the zero line), so the steady-state
+  // cost is one 64-bit add per piece; the row gather is recomputed only when the tap changes.
+  // (v3a recomputed rows, bounds and 64-bit products every K-tile: ~700 ALU instructions per wave
+  // per K-tile against 32 MFMAs — the loop was issue-bound, not memory- or MFMA-bound.)
+  constexpr int NP = LPT + (RBT > 0 ? 1 : 0);
+  const char* pc[NP];
+  int inc[NP];
+  const char* const zline = (const char*)&g_zero16;
+  const int src_cb = (ld_c ^ (ld_r & 7)) * 16;   // byte offset of this lane's source chunk
+  const int wave_row0 = wave * 8;                // first tile row written by this wave's DMA (+64*i)
+  int kt_next = kt_begin;                        // K-tile the pointers currently describe
+  int left;                                      // K-tiles until the A pointers must be regathered
 
-  // source chunk of this lane: LDS position ld_c holds chunk ld_c ^ (row & 7)
-  const int src_c = (ld_c ^ (ld_r & 7)) * 8;
-  const int wave_row0 = (tid >> 6) * 8;    // first tile row written by this wave's DMA (+32*i)
-
-  auto load_tile = [&](int kt, int buf) {
-    unsigned char* const dA = sA + buf * BM * ROW_BYTES + wave_row0 * ROW_BYTES;
-    unsigned char* const dB = sB + buf * BN * ROW_BYTES + wave_row0 * ROW_BYTES;
-    // ---- A rows ----
+  auto gather_a = [&](int kt) {                  // (re)compute pc[0..RA) for K-tile kt
     if (kt < T1) {
-      const int tap = nx_tap;
-      const int c0 = nx_c * BK + src_c;
+      const int tap = kt / cpt1;
+      const int cch = kt - tap * cpt1;
+      left = cpt1 - cch;
       int d0 = 0, d1 = 0;
       if (p.mode == VGEN_TAP_CONV3X3) {
         d0 = tap / 3;
@@ -160,84 +191,130 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const vgen_tapgemm_args p,
           ok = rs[i].base >= 0;
           row = rs[i].base;
         }
-        const void* src = ok ? (const void*)(A + row * p.lda + c0) : (const void*)&g_zero16;
-        glds16(src, dA + i * 32 * ROW_BYTES);
-      }
-      if (++nx_c == cpt1) {
-        nx_c = 0;
-        ++nx_tap;
+        pc[i] = ok ? (const char*)(A + row * p.lda + cch * BK) + src_cb : zline;
+        inc[i] = ok ? ROW_BYTES : 0;
       }
     } else {
-      const int c0 = (kt - T1) * BK + src_c;
+      left = KT - kt + 1;
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
-        const void* src = ((mvalid >> i) & 1u)
-                              ? (const void*)(A2 + (m0 + ld_r + 32 * i) * p.lda2 + c0)
-                              : (const void*)&g_zero16;
-        glds16(src, dA + i * 32 * ROW_BYTES);
+        const bool ok = (mvalid >> i) & 1u;
+        pc[i] = ok ? (const char*)(A2 + (int64_t)((unsigned)m0 + ld_r + RPP * i) * p.lda2 + (kt - T1) * BK) + src_cb
+                   : zline;
+        inc[i] = ok ? ROW_BYTES : 0;
       }
     }
-    // ---- W rows ----
-    const int64_t kofs = (int64_t)kt * BK + src_c;
+  };
+  gather_a(kt_begin);
 #pragma unroll
-    for (int i = 0; i < RB; ++i) {
-      const int n = n0 + ld_r + 32 * i;
-      const void* src = n < p.N ? (const void*)(W + (int64_t)n * ldw + kofs) : (const void*)&g_zero16;
-      glds16(src, dB + i * 32 * ROW_BYTES);
+  for (int i = 0; i < NP - RA; ++i) {
+    const int n = n0 + ld_r + RPP * i;
+    const bool ok = n < p.N;
+    pc[RA + i] = ok ? (const char*)(W + (int64_t)n * ldw + (int64_t)kt_begin * BK) + src_cb : zline;
+    inc[RA + i] = ok ? ROW_BYTES : 0;
+  }
+  auto advance = [&]() {                         // pointers -> next K-tile
+    ++kt_next;
+    if (--left == 0) {
+      if (kt_next < KT) gather_a(kt_next);
+    } else {
+#pragma unroll
+      for (int i = 0; i < RA; ++i) pc[i] += inc[i];
     }
+#pragma unroll
+    for (int i = RA; i < NP; ++i) pc[i] += inc[i];
+  };
+  // LDS destination (wave-uniform) of piece j in `stage`
+  auto piece_dst = [&](int stage, int j) -> unsigned char* {
+    unsigned char* const base = smem + stage * STAGE_BYTES + wave_row0 * ROW_BYTES;
+    return j < RA ? base + j * RPP * ROW_BYTES : base + (BM + (j - RA) * RPP) * ROW_BYTES;
+  };
+  auto load_tile = [&](int stage) {   // prologue: issue all pieces of the next K-tile back to back
+#pragma unroll
+    for (int j = 0; j < LPT; ++j) glds16(pc[j], piece_dst(stage, j));
+    if (RBT > 0 && w_tail) glds16(pc[NP - 1], piece_dst(stage, NP - 1));
+    advance();
   };
 
-  f32x4 acc[4][4];
+  f32x4 acc[NF][MF];
 #pragma unroll
-  for (int ni = 0; ni < 4; ++ni)
+  for (int ni = 0; ni < NF; ++ni)
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mi = 0; mi < MF; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // fragment read offsets: row (frag*16 + lr), chunk (ks*4 + lq) ^ (lr & 7)
   const int rd_row = lr * ROW_BYTES;
   const int sw = lr & 7;
 
-  auto compute = [&](int buf) {
-    const unsigned char* a = sA + buf * BM * ROW_BYTES + wm * 64 * ROW_BYTES + rd_row;
-    const unsigned char* b = sB + buf * BN * ROW_BYTES + wn * 64 * ROW_BYTES + rd_row;
+  // Multiply one staged K-tile and, interleaved with the MFMAs, issue the DMA pieces of the tile
+  // two steps ahead.  An LDS-DMA instruction occupies the CU's single texture-address path for
+  // ~16-25 cycles (1 KiB at <= 64 B/clk) and stalls the issuing wave ~100 cycles; issued in one
+  // burst by all 8 waves right after the barrier (v3a) the DMA phase and the MFMA phase simply
+  // added up (ablation: 142 us compute-only + 116 us DMA-only - 41 us fixed = 207 us measured at
+  // 4096^3).  Spread one piece per MFMA group, the partner wave on the SIMD keeps the matrix pipe
+  // busy while this wave waits on the address path.
+  auto compute = [&](int stage, bool prefetch, int stage_pf) {
+    const unsigned char* a = smem + stage * STAGE_BYTES + wm * WTM * ROW_BYTES + rd_row;
+    const unsigned char* b = smem + stage * STAGE_BYTES + BM * ROW_BYTES + wn * WTN * ROW_BYTES + rd_row;
+    u32x4 wf[2][NF], xf[2][MF];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int co = ((ks * 4 + lq) ^ sw) << 4;
-      u32x4 wf[4], xf[4];
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) wf[ni] = *(const u32x4*)(b + ni * 16 * ROW_BYTES + co);
+      for (int ni = 0; ni < NF; ++ni) wf[ks][ni] = *(const u32x4*)(b + ni * 16 * ROW_BYTES + co);
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) xf[mi] = *(const u32x4*)(a + mi * 16 * ROW_BYTES + co);
-#pragma unroll
-      for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) acc[ni][mi] = T::mfma32(wf[ni], xf[mi], acc[ni][mi]);
+      for (int mi = 0; mi < MF; ++mi) xf[ks][mi] = *(const u32x4*)(a + mi * 16 * ROW_BYTES + co);
     }
+    constexpr int NMF = 2 * NF * MF;                 // MFMAs per K-tile per wave
+    constexpr int GRP = NMF / NP;                    // MFMAs between two DMA pieces (>= NP slots)
+    static_assert(GRP >= 1 && (NMF + GRP - 1) / GRP >= NP, "not enough MFMA groups for the DMA pieces");
+    int piece = 0;
+#pragma unroll
+    for (int i = 0; i < NMF; ++i) {
+      const int ks = i / (NF * MF), r = i % (NF * MF), ni = r / MF, mi = r % MF;
+      if (i % GRP == 0) {
+        if (prefetch) {
+          if (piece < LPT) glds16(pc[piece], piece_dst(stage_pf, piece));
+          else if (RBT > 0 && piece == NP - 1 && w_tail) glds16(pc[NP - 1], piece_dst(stage_pf, NP - 1));
+        }
+        ++piece;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      acc[ni][mi] = T::mfma32(wf[ks][ni], xf[ks][mi], acc[ni][mi]);
+    }
+    if (prefetch) advance();
   };
 
-  // ---- main loop: one barrier per K-tile ------------------------------------------------
-  // The DMA is tracked by vmcnt; the explicit wait + barrier publishes a landed tile to all waves
-  // and (WAR) guarantees every wave finished reading the buffer the next DMA overwrites.
-  load_tile(kt_begin, 0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int buf = (kt - kt_begin) & 1;
-    if (kt + 1 < kt_end) load_tile(kt + 1, buf ^ 1);
-    compute(buf);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+  // ---- main loop: 3-stage DMA ring, one barrier per K-tile, counted vmcnt --------------------
+  // Iteration `it`:  wait until tile `it` has landed (the DMA of tile it+1 may stay in flight),
+  // barrier (publishes tile `it` of every wave AND proves every wave finished reading the stage
+  // that tile it+2 overwrites, last read in iteration it-1), issue tile it+2, multiply tile it.
+  if (nk > 0) load_tile(0);
+  if (nk > 1) load_tile(1);
+  int st_c = 0, st_l = 2;   // stage to compute / stage to load into
+  for (int it = 0; it < nk; ++it) {
+    if (it + 1 < nk) {
+      if (w_tail) wait_vmcnt<LPT + 1>();
+      else wait_vmcnt<LPT>();
+    } else {
+      wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    compute(st_c, it + 2 < nk, st_l);
+    st_c = st_c == STAGES - 1 ? 0 : st_c + 1;
+    st_l = st_l == STAGES - 1 ? 0 : st_l + 1;
   }
 
   if (splitk > 1) {   // raw fp32 partial tile -> workspace [split][M][N]; epilogue in the reducer
     float* const wsp = ws + (int64_t)split * p.M * p.N;
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi) {
-      const int64_t m = m0 + wm * 64 + mi * 16 + lr;
+    for (int mi = 0; mi < MF; ++mi) {
+      const int64_t m = m0 + wm * WTM + mi * 16 + lr;
       if (m >= p.M) continue;
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + wn * 64 + ni * 16 + lq * 4;
+      for (int ni = 0; ni < NF; ++ni) {
+        const int n = n0 + wn * WTN + ni * 16 + lq * 4;
         if (n < p.N) *(f32x4*)(wsp + m * p.N + n) = acc[ni][mi];
       }
     }
@@ -254,14 +331,14 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const vgen_tapgemm_args p,
   uint16_t* const oh = (uint16_t*)p.out;
 
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
-    const int64_t m = m0 + wm * 64 + mi * 16 + lr;
+  for (int mi = 0; mi < MF; ++mi) {
+    const int64_t m = m0 + wm * WTM + mi * 16 + lr;
     if (m >= p.M) continue;
     const float* rbp = p.rowbias ? p.rowbias + (m / p.rows_per_rb) * p.rowbias_ld : nullptr;
     if (!geglu) {
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) {
-        const int n = n0 + wn * 64 + ni * 16 + lq * 4;
+      for (int ni = 0; ni < NF; ++ni) {
+        const int n = n0 + wn * WTN + ni * 16 + lq * 4;
         if (n >= p.N) continue;
         f32x4 v = acc[ni][mi];
         if (vec) {
@@ -286,13 +363,13 @@ __global__ __launch_bounds__(256) void tapgemm_kernel(const vgen_tapgemm_args p,
           }
         }
       }
-    } else {
+    } else if constexpr (NF % 2 == 0) {
       // packed columns: fragment pairs (value, gate) = (ni even, ni odd)
 #pragma unroll
-      for (int np = 0; np < 2; ++np) {
-        const int pn = n0 + wn * 64 + np * 32 + lq * 4;  // packed index of the value lanes
+      for (int np = 0; np < NF / 2; ++np) {
+        const int pn = n0 + wn * WTN + np * 32 + lq * 4;  // packed index of the value lanes
         if (pn >= p.N) continue;
-        const int j = (n0 + wn * 64) / 2 + np * 16 + lq * 4;
+        const int j = (n0 + wn * WTN) / 2 + np * 16 + lq * 4;
         f32x4 val = acc[2 * np][mi];
         f32x4 gat = acc[2 * np + 1][mi];
         if (p.bias) {
@@ -346,30 +423,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vgen_tapgemm_a
   else *(u32x2*)((uint16_t*)p.out + m * p.ldo + j) = pack4<T>(v.x, v.y, v.z, v.w);
 }
 
+int pick_bn(const vgen_tapgemm_args& a) {
+  if (a.N % 128 == 0) return 128;
+  if (a.N % 160 == 0 && a.epilogue != VGEN_EPI_GEGLU) return 160;
+  return 64;
+}
+
 // Deterministic split-K plan: only for launches that cannot fill the chip and whose epilogue
 // operands are 16-byte vectorisable.
 int plan_splitk(const vgen_tapgemm_args& a) {
-  const bool wide = (a.N % 128 == 0);
-  const int BM = wide ? 128 : 256, BN = wide ? 128 : 64;
+  const int BN = pick_bn(a);
   const int64_t tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
   const int KT = a.taps * (a.C1 / 64) + a.C2 / 64;
   const int n_out = a.epilogue == VGEN_EPI_GEGLU ? a.N / 2 : a.N;
   const bool vec = (a.N % 4 == 0) && (n_out % 4 == 0) && (a.ldo % 4 == 0) &&
                    (a.residual == nullptr || a.ldr % 4 == 0) &&
                    (a.rowbias == nullptr || a.rowbias_ld % 4 == 0);
-  if (!vec || tiles >= 160 || KT < 16) return 1;
-  int64_t s = (384 + tiles - 1) / tiles;
+  if (!vec || tiles >= 200 || KT < 16) return 1;
+  int64_t s = (256 + tiles - 1) / tiles;
   if (s > KT / 8) s = KT / 8;
   if (s > 32) s = 32;
   return s < 2 ? 1 : (int)s;
 }
 
-template <typename T, int BM, int BN>
+template <typename T, int BN>
 int launch(const vgen_tapgemm_args& a, hipStream_t stream) {
-  constexpr size_t lds = 2 * (size_t)(BM + BN) * ROW_BYTES;
+  constexpr size_t lds = (size_t)STAGES * (BM + BN) * ROW_BYTES;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)tapgemm_kernel<T, BM, BN>,
+    hipError_t e = hipFuncSetAttribute((const void*)tapgemm_kernel<T, BN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       vgen_set_error("tapgemm: hipFuncSetAttribute(%zu B LDS) failed: %s", lds,
@@ -389,7 +471,7 @@ int launch(const vgen_tapgemm_args& a, hipStream_t stream) {
   int splitk = plan_splitk(a);
   if (splitk > 1 && (a.ws == nullptr || a.ws_bytes < (size_t)splitk * a.M * a.N * sizeof(float)))
     splitk = 1;   // caller did not provide the workspace: still correct, just fewer blocks
-  hipLaunchKernelGGL((tapgemm_kernel<T, BM, BN>), dim3((unsigned)grid, (unsigned)splitk), dim3(256), lds,
+  hipLaunchKernelGGL((tapgemm_kernel<T, BN>), dim3((unsigned)grid, (unsigned)splitk), dim3(NT), lds,
                      stream, a, splitk, (float*)a.ws);
   int rc = vgen_check_launch("tapgemm");
   if (rc || splitk == 1) return rc;
@@ -398,6 +480,15 @@ int launch(const vgen_tapgemm_args& a, hipStream_t stream) {
   hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
                      stream, a, splitk, (const float*)a.ws);
   return vgen_check_launch("tapgemm(splitk reduce)");
+}
+
+template <typename T>
+int dispatch(const vgen_tapgemm_args& a, hipStream_t s) {
+  switch (pick_bn(a)) {
+    case 128: return launch<T, 128>(a, s);
+    case 160: return launch<T, 160>(a, s);
+    default: return launch<T, 64>(a, s);
+  }
 }
 
 }  // namespace
@@ -450,7 +541,7 @@ extern "C" int vgen_tapgemm(const vgen_tapgemm_args* args, void* stream) {
       vgen_set_error("tapgemm: unknown mode %d", a.mode);
       return VGEN_E_BADARG;
   }
-  VGEN_REQUIRE(a.M < (1LL << 31), "tapgemm: M overflows int32 row index");
+  VGEN_REQUIRE(a.M + 256 < (1LL << 31), "tapgemm: M overflows int32 row index");
   if (a.epilogue == VGEN_EPI_GEGLU) {
     VGEN_REQUIRE(a.N % 64 == 0 && a.rowbias == nullptr && (a.ldo % 4 == 0) &&
                      (a.residual == nullptr || a.ldr % 4 == 0),
@@ -459,10 +550,5 @@ extern "C" int vgen_tapgemm(const vgen_tapgemm_args* args, void* stream) {
     VGEN_REQUIRE(a.epilogue == VGEN_EPI_NONE, "tapgemm: unknown epilogue");
   }
   hipStream_t s = (hipStream_t)stream;
-  const bool wide = (a.N % 128 == 0);
-  if (a.dtype == VGEN_BF16) {
-    return wide ? launch<BF16, 128, 128>(a, s) : launch<BF16, 256, 64>(a, s);
-  } else {
-    return wide ? launch<F16, 128, 128>(a, s) : launch<F16, 256, 64>(a, s);
-  }
+  return a.dtype == VGEN_BF16 ? dispatch<BF16>(a, s) : dispatch<F16>(a, s);
 }
