@@ -41,7 +41,7 @@ def test_struct_layout_matches_header():
         decl = decl.strip()
         if not decl:
             continue
-        decl = re.sub(r"^(const\s+)?(void|float|int32_t|int64_t)\s*\*?", "", decl)
+        decl = re.sub(r"^(const\s+)?(void|float|int32_t|int64_t|size_t)\s*\*?", "", decl)
         names += [n.strip(" *") for n in decl.split(",")]
     assert names == [f[0] for f in lib.TapGemmArgs._fields_]
     body = re.search(r"typedef struct vgen_attn_args \{(.*?)\} vgen_attn_args;", src, re.S).group(1)
@@ -50,7 +50,7 @@ def test_struct_layout_matches_header():
         decl = decl.strip()
         if not decl:
             continue
-        decl = re.sub(r"^(const\s+)?(void|float|int32_t|int64_t)\s*\*?", "", decl)
+        decl = re.sub(r"^(const\s+)?(void|float|int32_t|int64_t|size_t)\s*\*?", "", decl)
         names += [n.strip(" *") for n in decl.split(",")]
     assert names == [f[0] for f in lib.AttnArgs._fields_]
 
