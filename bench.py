@@ -192,12 +192,26 @@ def main():
         torch.cuda._sleep(int(4e8))     # let the host run ahead so event pairs bracket GPU time only
         diff.ddim_sample(xs, t_buf[:1], model, kw1, guide_scale=9.0, ddim_timesteps=50, eta=0.0)
         torch.cuda.synchronize()
-        recs = ops.KERNEL_PROFILE
+        allrecs = ops.KERNEL_PROFILE
         ops.KERNEL_PROFILE = None
+        recs = [r for r in allrecs if r[0] == "tapgemm"]
         diff.partition = part
         ms = [r[1].elapsed_time(r[2]) for r in recs]
         fl = [r[3] for r in recs]
         if args.dump_shapes:
+            other = {}
+            for r in allrecs:
+                if r[0] == "tapgemm":
+                    continue
+                a = other.setdefault((r[0],) + tuple(r[4]), [0, 0.0, 0.0])
+                a[0] += 1
+                a[1] += r[1].elapsed_time(r[2])
+                a[2] += r[3]
+            orows = sorted(([list(k), v[0], round(v[1], 4), round(v[2] / (v[1] * 1e-3) / 1e9, 1)] for k, v in other.items()),
+                           key=lambda r: -r[2])
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "other_shapes.json"), "w") as f:
+                json.dump({"cols": ["(op,shape...)", "launches", "ms", "GB/s or GFLOP/s"], "rows": orows}, f, indent=0)
             agg = {}
             for r, m in zip(recs, ms):
                 a = agg.setdefault(r[4], [0, 0.0, 0.0])

@@ -82,8 +82,21 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the 16-bit output rounding):
+// ~12 instructions instead of libm erff's ~40 — the GEGLU epilogue evaluates 32 per lane per tile.
+__device__ __forceinline__ float erf_as(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(1.0f + 0.3275911f * ax);
+  float p = 1.061405429f;
+  p = p * t - 1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t - 0.284496736f;
+  p = p * t + 0.254829592f;
+  const float r = 1.0f - p * t * __expf(-ax * ax);
+  return copysignf(r, x);
+}
 __device__ __forceinline__ float gelu_erf_f(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+  return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
 }
 
 // ---- host-side error plumbing (defined in cabi.cpp) -------------------------------------

@@ -76,6 +76,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(
     ss[k] = f32x4{0, 0, 0, 0};
   }
   if (active) {
+#pragma unroll 4
     for (int64_t r = r_begin + rowlane; r < r_end; r += g.rpb) {
       const int64_t row = nb * S + r;
 #pragma unroll
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(
       }
     }
   }
+#pragma unroll 4
   for (int64_t r = r_begin + rowlane; r < r_end; r += g.rpb) {
     const int64_t row = nb * S + r;
 #pragma unroll
@@ -213,56 +215,69 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(
   }
 }
 
-int gn_nsplit(int64_t nb, int64_t S) {
-  // aim for >= ~1024 blocks overall, >= 32 rows per block, <= 512 splits per batch
-  int64_t want = (1024 + nb - 1) / nb;
-  int64_t by_rows = (S + 31) / 32;
-  int64_t ns = want < by_rows ? want : by_rows;
+int gn_nsplit(int64_t nb, int64_t S, int C) {
+  // ~16 K elements (64 KiB of fp32) per block, but at least ~1024 blocks overall when the tensor
+  // allows it (>= 2 rows per block): the 4x7 / 8x14 levels are latency-bound, not bandwidth-bound.
+  int64_t rows = 16384 / C;
+  if (rows < 2) rows = 2;
+  int64_t ns = (S + rows - 1) / rows;
+  const int64_t want = (1024 + nb - 1) / nb;
+  if (ns < want) ns = want;
+  const int64_t cap = (S + 1) / 2;
+  if (ns > cap) ns = cap;
   if (ns < 1) ns = 1;
-  if (ns > 512) ns = 512;
+  if (ns > 1024) ns = 1024;
   return (int)ns;
 }
 
-// ---- LayerNorm: one wave per row, two-pass from registers --------------------------------
-constexpr int LN_MAX_SLOTS = 8;  // d <= 2048
+// ---- LayerNorm: LPR lanes per row (16 / 32 / 64), two-pass from registers ------------------
+// d = 320..1280 in the UNet: one 64-lane wave per 1.25 KiB row left most lanes idle and one load in
+// flight per wave (1.2 TB/s measured); with 16 lanes per row a wave streams 4 rows at once.
+constexpr int LN_MAX_SLOTS = 8;  // float4 slots per lane: d <= 4 * 8 * LPR
 
-template <typename T>
+template <typename T, int LPR>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t M,
                                                         int d, float eps,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
                                                         uint16_t* __restrict__ y) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= M) return;
+  constexpr int RPB = 256 / LPR;  // rows per block
+  const int sub = threadIdx.x % LPR;
+  const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
+  const bool live = row < M;
   const int nslots = d >> 2;
-  const float* xr = x + row * d;
+  const float* xr = x + (live ? row : 0) * d;
   f32x4 v[LN_MAX_SLOTS];
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < LN_MAX_SLOTS; ++k) {
-    const int slot = lane + 64 * k;
+    const int slot = sub + LPR * k;
     v[k] = f32x4{0, 0, 0, 0};
     if (slot < nslots) {
       v[k] = *(const f32x4*)(xr + slot * 4);
       s += (v[k].x + v[k].y) + (v[k].z + v[k].w);
     }
   }
-  const float mean = wave_sum(s) / (float)d;
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  const float mean = s / (float)d;
   float q = 0.f;
 #pragma unroll
   for (int k = 0; k < LN_MAX_SLOTS; ++k) {
-    const int slot = lane + 64 * k;
+    const int slot = sub + LPR * k;
     if (slot < nslots) {
       const f32x4 c = v[k] - mean;
       q += (c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w);
     }
   }
-  const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)d + eps);
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = 1.0f / sqrtf(q / (float)d + eps);
+  if (!live) return;
   uint16_t* yr = y + row * d;
 #pragma unroll
   for (int k = 0; k < LN_MAX_SLOTS; ++k) {
-    const int slot = lane + 64 * k;
+    const int slot = sub + LPR * k;
     if (slot < nslots) {
       const f32x4 ga = *(const f32x4*)(gamma + slot * 4);
       const f32x4 be = *(const f32x4*)(beta + slot * 4);
@@ -272,10 +287,26 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   }
 }
 
+template <typename T, int LPR>
+void launch_ln(const float* x, int64_t M, int d, float eps, const float* gamma, const float* beta,
+               uint16_t* y, hipStream_t s) {
+  const int64_t grid = (M + 256 / LPR - 1) / (256 / LPR);
+  hipLaunchKernelGGL((layernorm_kernel<T, LPR>), dim3((unsigned)grid), dim3(256), 0, s, x, M, d, eps,
+                     gamma, beta, y);
+}
+
+template <typename T>
+void dispatch_ln(const float* x, int64_t M, int d, float eps, const float* gamma, const float* beta,
+                 uint16_t* y, hipStream_t s) {
+  if (d <= 512) launch_ln<T, 16>(x, M, d, eps, gamma, beta, y, s);
+  else if (d <= 1024) launch_ln<T, 32>(x, M, d, eps, gamma, beta, y, s);
+  else launch_ln<T, 64>(x, M, d, eps, gamma, beta, y, s);
+}
+
 }  // namespace
 
 extern "C" size_t vgen_groupnorm_ws_bytes(int64_t nb, int64_t S) {
-  const int ns = gn_nsplit(nb, S);
+  const int ns = 1024;   // upper bound of gn_nsplit (independent of C so callers need not pass it)
   return (size_t)(nb * ns * GN_G * 3 + nb * GN_G * 2) * sizeof(float);
 }
 
@@ -304,7 +335,7 @@ extern "C" int vgen_groupnorm(const float* x1, int32_t C1, const float* x2, int3
   const int nslots = C / 4;
   const int rpb = nslots <= GN_THREADS ? GN_THREADS / nslots : 1;
   VGEN_REQUIRE(rpb * C <= 3072, "groupnorm: internal LDS bound");
-  const int ns = gn_nsplit(nb, S);
+  const int ns = gn_nsplit(nb, S, C);
   float* part = ws;
   float* stat = ws + nb * ns * GN_G * 3;
   hipStream_t s = (hipStream_t)stream;
@@ -335,15 +366,9 @@ extern "C" int vgen_layernorm(const float* x, int64_t M, int32_t d, float eps, c
                    vgen_aligned16(beta),
                "layernorm: alignment");
   if (M <= 0) return 0;
-  const int64_t grid = (M + 3) / 4;
-  VGEN_REQUIRE(grid < (1LL << 31), "layernorm: M too large");
+  VGEN_REQUIRE(M < (1LL << 32), "layernorm: M too large");
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == VGEN_BF16) {
-    hipLaunchKernelGGL(layernorm_kernel<BF16>, dim3((unsigned)grid), dim3(256), 0, s, x, M, d, eps,
-                       gamma, beta, (uint16_t*)y);
-  } else {
-    hipLaunchKernelGGL(layernorm_kernel<F16>, dim3((unsigned)grid), dim3(256), 0, s, x, M, d, eps,
-                       gamma, beta, (uint16_t*)y);
-  }
+  if (dtype == VGEN_BF16) dispatch_ln<BF16>(x, M, d, eps, gamma, beta, (uint16_t*)y, s);
+  else dispatch_ln<F16>(x, M, d, eps, gamma, beta, (uint16_t*)y, s);
   return vgen_check_launch("layernorm");
 }

@@ -423,27 +423,46 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vgen_tapgemm_a
   else *(u32x2*)((uint16_t*)p.out + m * p.ldo + j) = pack4<T>(v.x, v.y, v.z, v.w);
 }
 
-int pick_bn(const vgen_tapgemm_args& a) {
-  if (a.N % 128 == 0) return 128;
-  if (a.N % 160 == 0 && a.epilogue != VGEN_EPI_GEGLU) return 160;
-  return 64;
-}
+// ---- launch planning ---------------------------------------------------------------------------
+// One block per CU and 256-row tiles make tile-count quantisation expensive (280 tiles = 2 rounds
+// at 55 % fill), so the column tile BN and the split-K factor are chosen together from a small
+// cost model (microseconds; constants fitted to profiles/r01_v3_tapgemm_shapes.json):
+//   cost = rounds(tiles * s) * (ceil(KT / s) * t_ktile(BN) + t_tile) + [s > 1] * reduce(s)
+struct Plan {
+  int bn;
+  int splitk;
+};
 
-// Deterministic split-K plan: only for launches that cannot fill the chip and whose epilogue
-// operands are 16-byte vectorisable.
-int plan_splitk(const vgen_tapgemm_args& a) {
-  const int BN = pick_bn(a);
-  const int64_t tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+Plan make_plan(const vgen_tapgemm_args& a) {
+  const bool geglu = a.epilogue == VGEN_EPI_GEGLU;
   const int KT = a.taps * (a.C1 / 64) + a.C2 / 64;
-  const int n_out = a.epilogue == VGEN_EPI_GEGLU ? a.N / 2 : a.N;
+  const int n_out = geglu ? a.N / 2 : a.N;
   const bool vec = (a.N % 4 == 0) && (n_out % 4 == 0) && (a.ldo % 4 == 0) &&
                    (a.residual == nullptr || a.ldr % 4 == 0) &&
                    (a.rowbias == nullptr || a.rowbias_ld % 4 == 0);
-  if (!vec || tiles >= 200 || KT < 16) return 1;
-  int64_t s = (256 + tiles - 1) / tiles;
-  if (s > KT / 8) s = KT / 8;
-  if (s > 32) s = 32;
-  return s < 2 ? 1 : (int)s;
+  int cands[2], nc = 0;
+  if (a.N % 128 == 0) cands[nc++] = 128;
+  if (a.N % 160 == 0 && !geglu) cands[nc++] = 160;
+  if (nc == 0) cands[nc++] = 64;
+  const int64_t tiles_m = (a.M + BM - 1) / BM;
+  const int smax = vec ? (KT / 4 < 32 ? KT / 4 : 32) : 1;
+  Plan best{cands[0], 1};
+  double best_cost = 1e30;
+  for (int c = 0; c < nc; ++c) {
+    const int bn = cands[c];
+    const double t_ktile = bn == 160 ? 1.45 : (bn == 128 ? 1.2 : 0.75);
+    const int64_t tiles = tiles_m * ((a.N + bn - 1) / bn);
+    for (int s = 1; s <= (smax < 1 ? 1 : smax); ++s) {
+      const int64_t rounds = (tiles * s + 255) / 256;
+      double cost = (double)rounds * (((KT + s - 1) / s) * t_ktile + 6.0);
+      if (s > 1) cost += 5.0 + (double)(s + 1) * a.M * a.N * 4.0 / 3.0e6;   // partials at ~3 TB/s
+      if (cost < best_cost - 1e-9) {
+        best_cost = cost;
+        best = Plan{bn, s};
+      }
+    }
+  }
+  return best;
 }
 
 template <typename T, int BN>
@@ -468,7 +487,7 @@ int launch(const vgen_tapgemm_args& a, hipStream_t stream) {
     vgen_set_error("tapgemm: grid too large");
     return VGEN_E_BADARG;
   }
-  int splitk = plan_splitk(a);
+  int splitk = make_plan(a).splitk;
   if (splitk > 1 && (a.ws == nullptr || a.ws_bytes < (size_t)splitk * a.M * a.N * sizeof(float)))
     splitk = 1;   // caller did not provide the workspace: still correct, just fewer blocks
   hipLaunchKernelGGL((tapgemm_kernel<T, BN>), dim3((unsigned)grid, (unsigned)splitk), dim3(NT), lds,
@@ -484,7 +503,7 @@ int launch(const vgen_tapgemm_args& a, hipStream_t stream) {
 
 template <typename T>
 int dispatch(const vgen_tapgemm_args& a, hipStream_t s) {
-  switch (pick_bn(a)) {
+  switch (make_plan(a).bn) {
     case 128: return launch<T, 128>(a, s);
     case 160: return launch<T, 160>(a, s);
     default: return launch<T, 64>(a, s);
@@ -495,7 +514,7 @@ int dispatch(const vgen_tapgemm_args& a, hipStream_t s) {
 
 extern "C" size_t vgen_tapgemm_ws_bytes(const vgen_tapgemm_args* args) {
   if (!args || args->N <= 0 || args->M <= 0 || args->C1 <= 0 || args->C1 % 64 || args->C2 % 64) return 0;
-  const int s = plan_splitk(*args);
+  const int s = make_plan(*args).splitk;
   return s > 1 ? (size_t)s * args->M * args->N * sizeof(float) : 0;
 }
 

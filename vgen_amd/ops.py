@@ -98,6 +98,25 @@ class HipBackend:
                 "vgen_amd hot path needs device tensors (got %s); there is no CPU fallback" % t.device)
         return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
 
+    class _Prof:
+        """Brackets a launch with HIP events on the launch stream when KERNEL_PROFILE is a list."""
+        def __init__(self, name, work, meta):
+            self.rec = KERNEL_PROFILE
+            self.name, self.work, self.meta = name, work, meta
+
+        def __enter__(self):
+            if self.rec is not None:
+                self.e0 = torch.cuda.Event(enable_timing=True)
+                self.e1 = torch.cuda.Event(enable_timing=True)
+                self.e0.record()
+            return self
+
+        def __exit__(self, *exc):
+            if self.rec is not None:
+                self.e1.record()
+                self.rec.append((self.name, self.e0, self.e1, self.work, self.meta))
+            return False
+
     # -- norms -----------------------------------------------------------------------------
     def groupnorm(self, x1, x2, nb, S, groups, eps, gamma, beta, silu, want_raw, dt):
         C1 = x1.shape[1]
@@ -109,17 +128,20 @@ class HipBackend:
         raw = torch.empty_like(y) if want_raw else None
         nbytes = self.lib.vgen_groupnorm_ws_bytes(nb, S)
         ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x1.device)
-        rc = self.lib.vgen_groupnorm(_ptr(x1), C1, _ptr(x2), C2, nb, S, groups, float(eps),
-                                     _ptr(gamma), _ptr(beta), int(bool(silu)), _ptr(y), _ptr(raw),
-                                     _ENUM[dt], _ptr(ws), nbytes, self._stream(x1))
+        nbytes_moved = rows * (C1 + C2) * (4 + 4 + 2 + (2 if want_raw else 0))
+        with self._Prof("groupnorm", nbytes_moved, (nb, S, C1 + C2, int(want_raw))):
+            rc = self.lib.vgen_groupnorm(_ptr(x1), C1, _ptr(x2), C2, nb, S, groups, float(eps),
+                                         _ptr(gamma), _ptr(beta), int(bool(silu)), _ptr(y), _ptr(raw),
+                                         _ENUM[dt], _ptr(ws), nbytes, self._stream(x1))
         _lib.check(rc, "vgen_groupnorm")
         return y, raw
 
     def layernorm(self, x, gamma, beta, eps, dt):
         assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
         y = torch.empty(x.shape, dtype=dt, device=x.device)
-        rc = self.lib.vgen_layernorm(_ptr(x), x.shape[0], x.shape[1], float(eps), _ptr(gamma),
-                                     _ptr(beta), _ptr(y), _ENUM[dt], self._stream(x))
+        with self._Prof("layernorm", x.numel() * 6, tuple(x.shape)):
+            rc = self.lib.vgen_layernorm(_ptr(x), x.shape[0], x.shape[1], float(eps), _ptr(gamma),
+                                         _ptr(beta), _ptr(y), _ENUM[dt], self._stream(x))
         _lib.check(rc, "vgen_layernorm")
         return y
 
@@ -162,15 +184,9 @@ class HipBackend:
         if need:
             ws = torch.empty(need // 4, dtype=torch.float32, device=A.device)
             a.ws, a.ws_bytes = ws.data_ptr(), need
-        prof = KERNEL_PROFILE
-        if prof is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        rc = self.lib.vgen_tapgemm(C.byref(a), self._stream(A))
-        if prof is not None:
-            e1.record()
-            prof.append(("tapgemm", e0, e1, 2.0 * g.M * g.N * (g.taps * g.C1 + g.C2),
-                         (g.mode, g.M, g.N, g.taps * g.C1 + g.C2, g.epilogue, str(g.out_dtype))))
+        with self._Prof("tapgemm", 2.0 * g.M * g.N * (g.taps * g.C1 + g.C2),
+                        (g.mode, g.M, g.N, g.taps * g.C1 + g.C2, g.epilogue, str(g.out_dtype))):
+            rc = self.lib.vgen_tapgemm(C.byref(a), self._stream(A))
         _lib.check(rc, "vgen_tapgemm")
         return out
 
@@ -185,7 +201,9 @@ class HipBackend:
         a.v_rs, a.v_bo, a.v_bi = g.v_s
         a.o_rs, a.o_bo, a.o_bi = g.o_s
         a.scale = float(g.scale)
-        rc = self.lib.vgen_attention(C.byref(a), self._stream(g.q))
+        with self._Prof("attention", 4.0 * g.nbatch * g.heads * g.nq * g.nk * 64,
+                        (g.nbatch, g.heads, g.nq, g.nk)):
+            rc = self.lib.vgen_attention(C.byref(a), self._stream(g.q))
         _lib.check(rc, "vgen_attention")
         return g.out
 
@@ -204,7 +222,8 @@ class HipBackend:
     def act_cast(self, x, act, dt):
         assert x.dtype == torch.float32 and x.is_contiguous()
         y = torch.empty(x.shape, dtype=dt, device=x.device)
-        rc = self.lib.vgen_act_cast(_ptr(x), _ptr(y), x.numel(), int(act), _ENUM[dt], self._stream(x))
+        with self._Prof("act_cast", x.numel() * 6, (x.numel(),)):
+            rc = self.lib.vgen_act_cast(_ptr(x), _ptr(y), x.numel(), int(act), _ENUM[dt], self._stream(x))
         _lib.check(rc, "vgen_act_cast")
         return y
 
