@@ -253,26 +253,30 @@ def main():
                       "tflops_per_s": round(fps * VAE_DEC_TFLOP, 2)}
         del vae
 
-    # ---- CPU baseline: the oracle on the host cores, one full-size forward ---------------------------------
+    # ---- CPU baseline: the oracle on host cores, bounded sample -------------------------------------------
+    # Sample = the full-size UNetSD_T2VBase (1411 M params) on a 4-frame latent [1,4,4,32,56] — 1/4 of the
+    # 16-frame forward (conv/linear FLOPs are proportional to F) — scaled x4 to one forward, x2 to one
+    # CFG step.  32 threads: more threads made the oracle slower on the 256-core host (363 s per full
+    # forward with 256 threads in an earlier run).
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import torch_ref
         gold = torch.load(os.path.join(ROOT, "tests", "golden", "unet_t2v_full.pt"), map_location="cpu",
                           weights_only=False)
         sd = torch_ref.synth_state_dict(gold["shapes"], seed=0)
-        cores = os.cpu_count() or 1
+        cores = min(os.cpu_count() or 1, 32)
         torch.set_num_threads(cores)
         gen = torch.Generator("cpu").manual_seed(8888)
-        x = torch.randn(1, 4, 16, 32, 56, generator=gen)
+        x = torch.randn(1, 4, 16, 32, 56, generator=gen)[:, :, :4].contiguous()
         yy = torch.randn(1, 77, 1024, generator=gen)
         with torch.no_grad():
             t1 = time.perf_counter()
-            o = torch_ref.unet_forward(sd, x, torch.tensor([981]), yy, 320)
-            cpu_fwd = time.perf_counter() - t1
-        err = float((o - gold["out"].float()).norm() / gold["out"].float().norm())
-        res["cpu_baseline"] = {"value": round(1.0 / (2 * cpu_fwd), 5), "unit": "steps/s", "cores": cores,
+            torch_ref.unet_forward(sd, x, torch.tensor([981]), yy, 320)
+            cpu_s = time.perf_counter() - t1
+        fwd_s = 4.0 * cpu_s
+        res["cpu_baseline"] = {"value": round(1.0 / (2 * fwd_s), 5), "unit": "steps/s", "cores": cores,
                                "kind": "port",
-                               "sample": "1 full-size UNetSD_T2VBase forward (= half a CFG step), fp32, "
-                                         f"{cpu_fwd:.1f} s; oracle vs reference golden rel-L2 {err:.1e}"}
+                               "sample": "oracle (oracle/torch_ref.py, fp32) full-size UNet on a 4-frame latent "
+                                         f"[1,4,4,32,56]: {cpu_s:.1f} s, x4 frames x2 CFG branches per step"}
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
