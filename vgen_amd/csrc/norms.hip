@@ -119,42 +119,44 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(
   }
 }
 
-__global__ __launch_bounds__(GN_THREADS) void gn_finalize_kernel(const float* __restrict__ part,
-                                                                 int groups, int nsplit, float eps,
-                                                                 float* __restrict__ stat) {
-  // 8 lanes per group; lane j folds splits j, j+8, ... sequentially, then an 8-lane tree.
-  const int tid = threadIdx.x;
-  const int grp = tid >> 3;
-  const int j = tid & 7;
-  const int64_t nb = blockIdx.x;
+__global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part,
+                                                         int groups, int nsplit, float eps,
+                                                         float* __restrict__ stat) {
+  // one wave per (batch, group): lane j Chan-folds splits j, j+64, ... (<= 16 each), then a 6-step
+  // butterfly.  (The first version used 8 lanes per group in one block per batch: up to 128
+  // dependent steps — 17 us per launch, as slow as the streaming passes it sits between.)
+  const int lane = threadIdx.x;
+  const int grp = blockIdx.x;
+  const int64_t nb = blockIdx.y;
   float n = 0.f, mean = 0.f, m2 = 0.f;
-  if (grp < groups) {
-    for (int sp = j; sp < nsplit; sp += 8) {
-      const float* p = part + ((nb * nsplit + sp) * groups + grp) * 3;
-      const float nb_ = p[0], mb = p[1], m2b = p[2];
-      if (nb_ > 0.f) {
-        const float nt = n + nb_;
-        const float d = mb - mean;
-        mean += d * (nb_ / nt);
-        m2 += m2b + d * d * (n * nb_ / nt);
-        n = nt;
-      }
+  for (int sp = lane; sp < nsplit; sp += 64) {
+    const float* p = part + ((nb * nsplit + sp) * groups + grp) * 3;
+    const float nb_ = p[0], mb = p[1], m2b = p[2];
+    if (nb_ > 0.f) {
+      const float nt = n + nb_;
+      const float d = mb - mean;
+      mean += d * (nb_ / nt);
+      m2 += m2b + d * d * (n * nb_ / nt);
+      n = nt;
     }
   }
 #pragma unroll
-  for (int o = 1; o < 8; o <<= 1) {
+  for (int o = 1; o < 64; o <<= 1) {
     const float n2 = __shfl_xor(n, o, 64), mean2 = __shfl_xor(mean, o, 64),
                 m22 = __shfl_xor(m2, o, 64);
+    // symmetric form: both partners compute bit-identical results
     const float nt = n + n2;
     if (nt > 0.f) {
-      const float d = mean2 - mean;
-      const float w = n2 / nt;
-      m2 = m2 + m22 + d * d * (n * w);
-      mean = mean + d * w;
+      const float lo_n = (lane & o) ? n2 : n, hi_n = (lane & o) ? n : n2;
+      const float lo_m = (lane & o) ? mean2 : mean, hi_m = (lane & o) ? mean : mean2;
+      const float d = hi_m - lo_m;
+      const float w = hi_n / nt;
+      m2 = m2 + m22 + d * d * (lo_n * w);
+      mean = lo_m + d * w;
     }
     n = nt;
   }
-  if (grp < groups && j == 0) {
+  if (lane == 0) {
     const float var = n > 0.f ? m2 / n : 0.f;
     stat[(nb * groups + grp) * 2 + 0] = mean;
     stat[(nb * groups + grp) * 2 + 1] = 1.0f / sqrtf(var + eps);
@@ -344,8 +346,8 @@ extern "C" int vgen_groupnorm(const float* x1, int32_t C1, const float* x2, int3
                      part);
   int rc = vgen_check_launch("gn_stats");
   if (rc) return rc;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)nb), dim3(GN_THREADS), 0, s, part, groups,
-                     ns, eps, stat);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)groups, (unsigned)nb), dim3(64), 0, s, part,
+                     groups, ns, eps, stat);
   rc = vgen_check_launch("gn_finalize");
   if (rc) return rc;
   if (dtype == VGEN_BF16) {
