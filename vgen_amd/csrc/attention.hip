@@ -36,8 +36,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void flash_kernel(const vgen_attn_args p, int qtiles) {
   constexpr int BQ = 128, BKV = 64;
   constexpr int VS = 72;  // V^T row stride in elements (64 keys + 8 pad) -> 144 B
-  __shared__ __attribute__((aligned(16))) unsigned char sK[BKV * 128];      // [key][64 d] swizzled
-  __shared__ __attribute__((aligned(16))) uint16_t sVt[HD * VS];             // [d][key]
+  // double-buffered K / V^T tiles: the global loads of tile t+1 are issued before the MFMAs of
+  // tile t and written to the other buffer after them -> one barrier per tile, HBM/L2 latency
+  // hidden behind the compute (v1 was single-buffered with two barriers: latency-bound, 250 TF/s).
+  __shared__ __attribute__((aligned(16))) unsigned char sK[2][BKV * 128];   // [key][64 d] swizzled
+  __shared__ __attribute__((aligned(16))) uint16_t sVt[2][HD * VS];         // [d][key]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4;
@@ -79,37 +82,53 @@ __global__ __launch_bounds__(256) void flash_kernel(const vgen_attn_args p, int 
   const float c = p.scale * 1.44269504088896340736f;  // scores -> log2 domain
 
   // staging assignments
-  const int k_row = tid >> 2, k_ch = (tid & 3) * 2;  // K: row, two 16-B chunks
-  const int v_key = tid & 63, v_d0 = (tid >> 6) * 16;  // V: key, 16 d values (two 16-B chunks)
+  const int k_row = tid >> 2, k_ch = (tid & 3) * 2;      // K: row, two 16-B chunks
+  const int v_key = tid & 63, v_d0 = (tid >> 6) * 16;    // V: key, 16 d values (two 16-B chunks)
 
-  for (int kv0 = 0; kv0 < p.nk; kv0 += BKV) {
-    __syncthreads();  // previous tile fully consumed
-    {
-      u32x4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
-      if (kv0 + k_row < p.nk) {
-        const uint16_t* src = K + (int64_t)(kv0 + k_row) * p.k_rs + k_ch * 8;
-        a = *(const u32x4*)src;
-        b = *(const u32x4*)(src + 8);
-      }
-      unsigned char* dst = sK + k_row * 128;
-      *(u32x4*)(dst + (((k_ch) ^ (k_row & 7)) << 4)) = a;
-      *(u32x4*)(dst + (((k_ch + 1) ^ (k_row & 7)) << 4)) = b;
+  u32x4 rk0, rk1, rv0, rv1;
+  auto gload = [&](int kv0) {
+    rk0 = rk1 = rv0 = rv1 = u32x4{0u, 0u, 0u, 0u};
+    if (kv0 + k_row < p.nk) {
+      const uint16_t* src = K + (int64_t)(kv0 + k_row) * p.k_rs + k_ch * 8;
+      rk0 = *(const u32x4*)src;
+      rk1 = *(const u32x4*)(src + 8);
     }
-    {
-      u32x4 a = {0u, 0u, 0u, 0u}, b = {0u, 0u, 0u, 0u};
-      if (kv0 + v_key < p.nk) {
-        const uint16_t* src = V + (int64_t)(kv0 + v_key) * p.v_rs + v_d0;
-        a = *(const u32x4*)src;
-        b = *(const u32x4*)(src + 8);
-      }
-      const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    if (kv0 + v_key < p.nk) {
+      const uint16_t* src = V + (int64_t)(kv0 + v_key) * p.v_rs + v_d0;
+      rv0 = *(const u32x4*)src;
+      rv1 = *(const u32x4*)(src + 8);
+    }
+  };
+  auto lstore = [&](int buf) {
+    unsigned char* dst = sK[buf] + k_row * 128;
+    *(u32x4*)(dst + (((k_ch) ^ (k_row & 7)) << 4)) = rk0;
+    *(u32x4*)(dst + (((k_ch + 1) ^ (k_row & 7)) << 4)) = rk1;
+    // V^T[d][key]: pair the two keys of a lane pair into one dword per d (quad_perm 1,0,3,2 swap):
+    // even-key lanes write rows d0+2e, odd-key lanes rows d0+2e+1 -> 8 ds_write_b32 per thread
+    const uint32_t w[8] = {rv0.x, rv0.y, rv0.z, rv0.w, rv1.x, rv1.y, rv1.z, rv1.w};
+    const bool odd = v_key & 1;
+    uint32_t* vt = (uint32_t*)sVt[buf];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        sVt[(v_d0 + 2 * e) * VS + v_key] = (uint16_t)(w[e] & 0xffffu);
-        sVt[(v_d0 + 2 * e + 1) * VS + v_key] = (uint16_t)(w[e] >> 16);
-      }
+    for (int e = 0; e < 8; ++e) {
+      const uint32_t x = w[e];
+      const uint32_t y = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xf, 0xf, false);
+      const uint32_t out = odd ? ((y >> 16) | (x & 0xffff0000u)) : ((x & 0xffffu) | (y << 16));
+      const int row = v_d0 + 2 * e + (odd ? 1 : 0);
+      vt[(row * VS + (v_key & ~1)) >> 1] = out;
     }
-    __syncthreads();
+  };
+
+  const int ntile = (p.nk + BKV - 1) / BKV;
+  gload(0);
+  lstore(0);
+  __syncthreads();
+  for (int t = 0; t < ntile; ++t) {
+    const int kv0 = t * BKV;
+    const int buf = t & 1;
+    const bool more = t + 1 < ntile;
+    if (more) gload(kv0 + BKV);
+    const unsigned char* cK = sK[buf];
+    const uint16_t* cV = sVt[buf];
 
     // ---- S^T = K Q^T for both query fragments; K fragments shared ------------------------
     f32x4 s[2][4];
@@ -122,38 +141,42 @@ __global__ __launch_bounds__(256) void flash_kernel(const vgen_attn_args p, int 
       const int co = ((ks * 4 + lq) ^ (lr & 7)) << 4;
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf) {
-        const u32x4 kfrag = *(const u32x4*)(sK + (kf * 16 + lr) * 128 + co);
+        const u32x4 kfrag = *(const u32x4*)(cK + (kf * 16 + lr) * 128 + co);
         s[0][kf] = T::mfma32(kfrag, qf[0][ks], s[0][kf]);
         s[1][kf] = T::mfma32(kfrag, qf[1][ks], s[1][kf]);
       }
     }
 
     // ---- online softmax; lane (lq, lr) holds keys kv0 + 16*kf + 4*lq + r of query lr ------
+    const bool ragged = kv0 + BKV > p.nk;
     u32x4 pb[2][2];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
+      if (ragged) {   // block-uniform: only the last KV tile of a ragged sequence pays for the mask
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            s[f][kf][r] = (kv0 + kf * 16 + lq * 4 + r < p.nk) ? s[f][kf][r] : -INFINITY;
+      }
       float mx = -INFINITY;
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = kv0 + kf * 16 + lq * 4 + r;
-          const float v = key < p.nk ? s[f][kf][r] : -INFINITY;
-          s[f][kf][r] = v;
-          mx = fmaxf(mx, v);
-        }
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[f][kf][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[f], mx);  // finite: every tile has >= 1 valid key
-      const float alpha = exp2f((m_run[f] - m_new) * c);
+      const float alpha = fast_exp2((m_run[f] - m_new) * c);
       m_run[f] = m_new;
+      const float mc = m_new * c;
       float psum = 0.f;
       float pv[4][4];
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float e = exp2f((s[f][kf][r] - m_new) * c);
+          const float e = fast_exp2(s[f][kf][r] * c - mc);
           pv[kf][r] = e;
           psum += e;
         }
@@ -163,12 +186,12 @@ __global__ __launch_bounds__(256) void flash_kernel(const vgen_attn_args p, int 
       // B operand of the PV product for key-step st: keys {32st + 4lq + r} U {32st + 16 + 4lq + r}
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
-        u32x4 t;
-        t.x = pack2<T>(pv[2 * st][0], pv[2 * st][1]);
-        t.y = pack2<T>(pv[2 * st][2], pv[2 * st][3]);
-        t.z = pack2<T>(pv[2 * st + 1][0], pv[2 * st + 1][1]);
-        t.w = pack2<T>(pv[2 * st + 1][2], pv[2 * st + 1][3]);
-        pb[f][st] = t;
+        u32x4 tt;
+        tt.x = pack2<T>(pv[2 * st][0], pv[2 * st][1]);
+        tt.y = pack2<T>(pv[2 * st][2], pv[2 * st][3]);
+        tt.z = pack2<T>(pv[2 * st + 1][0], pv[2 * st + 1][1]);
+        tt.w = pack2<T>(pv[2 * st + 1][2], pv[2 * st + 1][3]);
+        pb[f][st] = tt;
       }
     }
 
@@ -177,13 +200,16 @@ __global__ __launch_bounds__(256) void flash_kernel(const vgen_attn_args p, int 
     for (int st = 0; st < 2; ++st)
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
-        const uint16_t* vr = sVt + (d * 16 + lr) * VS + st * 32 + lq * 4;
+        const uint16_t* vr = cV + (d * 16 + lr) * VS + st * 32 + lq * 4;
         const u32x2 lo = *(const u32x2*)vr;
         const u32x2 hi = *(const u32x2*)(vr + 16);
         const u32x4 vfrag = {lo.x, lo.y, hi.x, hi.y};
         o_acc[0][d] = T::mfma32(vfrag, pb[0][st], o_acc[0][d]);
         o_acc[1][d] = T::mfma32(vfrag, pb[1][st], o_acc[1][d]);
       }
+
+    if (more) lstore(buf ^ 1);
+    __syncthreads();
   }
 
   // ---- normalise and store: lane (lq, lr) owns O[q = lr][d = 16*dd + 4*lq + r] -------------

@@ -28,6 +28,14 @@ struct BF16 {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
   }
+  // two fp32 -> packed bf16 in ONE instruction (gfx950 v_cvt_pk_bf16_f32, round-to-nearest-even);
+  // the bit-twiddling from_f32() above costs ~6 VALU ops per value and made the attention
+  // softmax VALU-bound (SQ_ACTIVE_INST_VALU = 43 % of wave cycles at 2 waves / SIMD).
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+  }
   static __device__ __forceinline__ f32x4 mfma32(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),
                                                    __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
@@ -46,6 +54,9 @@ struct F16 {
   static __device__ __forceinline__ uint16_t from_f32(float f) {
     return __builtin_bit_cast(uint16_t, (_Float16)f);
   }
+  static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+    return (uint32_t)from_f32(lo) | ((uint32_t)from_f32(hi) << 16);
+  }
   static __device__ __forceinline__ f32x4 mfma32(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
                                                   __builtin_bit_cast(f16x8_t, b), c, 0, 0, 0);
@@ -58,7 +69,7 @@ struct F16 {
 
 template <typename T>
 __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-  return (uint32_t)T::from_f32(lo) | ((uint32_t)T::from_f32(hi) << 16);
+  return T::pack2(lo, hi);
 }
 
 template <typename T>
@@ -82,6 +93,8 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// raw v_exp_f32 (2^x): -inf -> 0, no denormal fix-up sequence (4 extra VALU ops per call in exp2f)
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 // erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the 16-bit output rounding):
 // ~12 instructions instead of libm erff's ~40 — the GEGLU epilogue evaluates 32 per lane per tile.
 __device__ __forceinline__ float erf_as(float x) {
