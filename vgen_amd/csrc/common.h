@@ -92,9 +92,10 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
 // raw v_exp_f32 (2^x): -inf -> 0, no denormal fix-up sequence (4 extra VALU ops per call in exp2f)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+
 // erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the 16-bit output rounding):
 // ~12 instructions instead of libm erff's ~40 — the GEGLU epilogue evaluates 32 per lane per tile.
 __device__ __forceinline__ float erf_as(float x) {
@@ -110,6 +111,29 @@ __device__ __forceinline__ float erf_as(float x) {
 }
 __device__ __forceinline__ float gelu_erf_f(float x) {
   return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752440f));
+}
+// value * gelu(gate) on 4 lanes-worth at once: written on f32x4 so the polynomial lowers to packed
+// v_pk_fma_f32 / v_pk_mul_f32 (2 floats per VALU op); exp / rcp stay scalar transcendentals.
+__device__ __forceinline__ f32x4 geglu4(f32x4 val, f32x4 g) {
+  const f32x4 x = g * 0.70710678118654752440f;
+  f32x4 ax, t, e;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ax[i] = fabsf(x[i]);
+  const f32x4 den = ax * 0.3275911f + 1.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) t[i] = __frcp_rn(den[i]);
+  f32x4 p = t * 1.061405429f - 1.453152027f;
+  p = p * t + 1.421413741f;
+  p = p * t - 0.284496736f;
+  p = p * t + 0.254829592f;
+  const f32x4 nx2 = ax * ax * -1.44269504088896340736f;   // exp(-x^2) = 2^(-x^2 * log2 e)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) e[i] = fast_exp2(nx2[i]);
+  const f32x4 r = 1.0f - p * t * e;                       // erf(|x|)
+  f32x4 er;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) er[i] = copysignf(r[i], x[i]);
+  return val * (g * 0.5f) * (er + 1.0f);
 }
 
 // ---- host-side error plumbing (defined in cabi.cpp) -------------------------------------
