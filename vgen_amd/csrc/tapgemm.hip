@@ -39,11 +39,12 @@ namespace {
 
 constexpr int BK = 64;          // K elements per tile (128 bytes per row)
 constexpr int ROW_BYTES = 128;  // BK * 2
-constexpr int STAGES = 3;
-constexpr int BM = 256;
-constexpr int WM = 4, WN = 2;   // wave grid
-constexpr int NT = WM * WN * 64;
-constexpr int RPP = NT / 8;     // tile rows covered by one DMA pass of the whole block (64)
+// Two block shapes (template parameters BM / WM / STAGES of the kernel):
+//   "big"   BM = 256, 4x2 waves (512 threads), 3-stage ring, one block per CU  — long-K GEMMs
+//   "small" BM = 128, 2x2 waves (256 threads), 2-stage ring, two blocks per CU — the two blocks are
+//           not barrier-coupled, so one block's MFMAs cover the other's fragment-read / epilogue
+//           bubbles, and 512 tile slots halve the tile-quantisation loss of short launches.
+constexpr int WN = 2;
 
 struct RowState {
   int base;  // LINEAR/TEMPORAL: source row m; CONV: img * Hi * Wi
@@ -68,9 +69,12 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename T, int BN>
-__global__ __launch_bounds__(NT) void tapgemm_kernel(const vgen_tapgemm_args p, const int splitk,
-                                                     float* __restrict__ ws) {
+template <typename T, int BM, int BN, int STAGES>
+__global__ __launch_bounds__(BM * 2) void tapgemm_kernel(const vgen_tapgemm_args p, const int splitk,
+                                                         float* __restrict__ ws) {
+  constexpr int WM = BM / 64;                   // waves along M (wave tile is 64 rows)
+  constexpr int NT = WM * WN * 64;              // threads (= 2 * BM)
+  constexpr int RPP = NT / 8;                   // tile rows covered by one DMA pass of the block
   constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile 64 x {64, 80, 32}
   constexpr int MF = WTM / 16, NF = WTN / 16;   // fragments per wave
   constexpr int RA = BM / RPP;                  // A DMA passes per tile (4)
@@ -285,15 +289,17 @@ __global__ __launch_bounds__(NT) void tapgemm_kernel(const vgen_tapgemm_args p, 
     if (prefetch) advance();
   };
 
-  // ---- main loop: 3-stage DMA ring, one barrier per K-tile, counted vmcnt --------------------
-  // Iteration `it`:  wait until tile `it` has landed (the DMA of tile it+1 may stay in flight),
-  // barrier (publishes tile `it` of every wave AND proves every wave finished reading the stage
-  // that tile it+2 overwrites, last read in iteration it-1), issue tile it+2, multiply tile it.
-  if (nk > 0) load_tile(0);
-  if (nk > 1) load_tile(1);
-  int st_c = 0, st_l = 2;   // stage to compute / stage to load into
+  // ---- main loop: STAGES-deep DMA ring, one barrier per K-tile, counted vmcnt ------------------
+  // Iteration `it`: wait until tile `it` has landed (with 3 stages the DMA of tile it+1 may stay in
+  // flight), barrier (publishes tile `it` of every wave AND proves every wave finished reading the
+  // stage that the next DMA overwrites, last read in iteration it-1), issue tile it+STAGES-1
+  // interleaved with the MFMAs of tile it.
+  constexpr int AHEAD = STAGES - 1;
+  for (int i = 0; i < AHEAD; ++i)
+    if (nk > i) load_tile(i);
+  int st_c = 0, st_l = AHEAD;   // stage to compute / stage to load into
   for (int it = 0; it < nk; ++it) {
-    if (it + 1 < nk) {
+    if (STAGES == 3 && it + 1 < nk) {
       if (w_tail) wait_vmcnt<LPT + 1>();
       else wait_vmcnt<LPT>();
     } else {
@@ -301,7 +307,7 @@ __global__ __launch_bounds__(NT) void tapgemm_kernel(const vgen_tapgemm_args p, 
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    compute(st_c, it + 2 < nk, st_l);
+    compute(st_c, it + AHEAD < nk, st_l);
     st_c = st_c == STAGES - 1 ? 0 : st_c + 1;
     st_l = st_l == STAGES - 1 ? 0 : st_l + 1;
   }
@@ -431,7 +437,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vgen_tapgemm_a
 // at 55 % fill), so the column tile BN and the split-K factor are chosen together from a small
 // cost model (microseconds; constants fitted to profiles/r01_v3_tapgemm_shapes.json):
 //   cost = rounds(tiles * s) * (ceil(KT / s) * t_ktile(BN) + t_tile) + [s > 1] * reduce(s)
+// relative K-step time and per-tile fixed cost of the small (128-row, 2 blocks / CU) shape
+constexpr double kSmallRel = 1.6;
+constexpr double kSmallFixed = 6.0;
+
 struct Plan {
+  int bm;
   int bn;
   int splitk;
 };
@@ -447,33 +458,40 @@ Plan make_plan(const vgen_tapgemm_args& a) {
   if (a.N % 128 == 0) cands[nc++] = 128;
   if (a.N % 160 == 0 && !geglu) cands[nc++] = 160;
   if (nc == 0) cands[nc++] = 64;
-  const int64_t tiles_m = (a.M + BM - 1) / BM;
+  static const int force_bm = getenv("VGEN_TAPGEMM_FORCE_BM") ? atoi(getenv("VGEN_TAPGEMM_FORCE_BM")) : 0;
   const int smax = vec ? (KT / 4 < 32 ? KT / 4 : 32) : 1;
-  Plan best{cands[0], 1};
+  Plan best{256, cands[0], 1};
   double best_cost = 1e30;
-  for (int c = 0; c < nc; ++c) {
-    const int bn = cands[c];
-    const double t_ktile = bn == 160 ? 1.45 : (bn == 128 ? 1.2 : 0.75);
-    const int64_t tiles = tiles_m * ((a.N + bn - 1) / bn);
-    for (int s = 1; s <= (smax < 1 ? 1 : smax); ++s) {
-      const int64_t rounds = (tiles * s + 255) / 256;
-      double cost = (double)rounds * (((KT + s - 1) / s) * t_ktile + 6.0);
-      if (s > 1) cost += 5.0 + (double)(s + 1) * a.M * a.N * 4.0 / 3.0e6;   // partials at ~3 TB/s
-      if (cost < best_cost - 1e-9) {
-        best_cost = cost;
-        best = Plan{bn, s};
+  for (int bm = 256; bm >= 128; bm -= 128) {
+    if (force_bm && bm != force_bm) continue;
+    const int64_t tiles_m = (a.M + bm - 1) / bm;
+    const int slots = bm == 256 ? 256 : 512;          // co-resident blocks on the chip
+    for (int c = 0; c < nc; ++c) {
+      const int bn = cands[c];
+      // time of one K-step of one block (us); a small block shares its CU with a second one
+      const double t_ktile = (bn == 160 ? 1.45 : (bn == 128 ? 1.2 : 0.75)) * (bm == 256 ? 1.0 : kSmallRel);
+      const double t_tile = bm == 256 ? 6.0 : kSmallFixed;
+      const int64_t tiles = tiles_m * ((a.N + bn - 1) / bn);
+      for (int s = 1; s <= (smax < 1 ? 1 : smax); ++s) {
+        const int64_t rounds = (tiles * s + slots - 1) / slots;
+        double cost = (double)rounds * (((KT + s - 1) / s) * t_ktile + t_tile);
+        if (s > 1) cost += 5.0 + (double)(s + 1) * a.M * a.N * 4.0 / 3.0e6;   // partials at ~3 TB/s
+        if (cost < best_cost - 1e-9) {
+          best_cost = cost;
+          best = Plan{bm, bn, s};
+        }
       }
     }
   }
   return best;
 }
 
-template <typename T, int BN>
-int launch(const vgen_tapgemm_args& a, hipStream_t stream) {
+template <typename T, int BM, int BN, int STAGES>
+int launch(const vgen_tapgemm_args& a, int splitk, hipStream_t stream) {
   constexpr size_t lds = (size_t)STAGES * (BM + BN) * ROW_BYTES;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)tapgemm_kernel<T, BN>,
+    hipError_t e = hipFuncSetAttribute((const void*)tapgemm_kernel<T, BM, BN, STAGES>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       vgen_set_error("tapgemm: hipFuncSetAttribute(%zu B LDS) failed: %s", lds,
@@ -490,11 +508,10 @@ int launch(const vgen_tapgemm_args& a, hipStream_t stream) {
     vgen_set_error("tapgemm: grid too large");
     return VGEN_E_BADARG;
   }
-  int splitk = make_plan(a).splitk;
   if (splitk > 1 && (a.ws == nullptr || a.ws_bytes < (size_t)splitk * a.M * a.N * sizeof(float)))
     splitk = 1;   // caller did not provide the workspace: still correct, just fewer blocks
-  hipLaunchKernelGGL((tapgemm_kernel<T, BN>), dim3((unsigned)grid, (unsigned)splitk), dim3(NT), lds,
-                     stream, a, splitk, (float*)a.ws);
+  hipLaunchKernelGGL((tapgemm_kernel<T, BM, BN, STAGES>), dim3((unsigned)grid, (unsigned)splitk),
+                     dim3(BM * 2), lds, stream, a, splitk, (float*)a.ws);
   int rc = vgen_check_launch("tapgemm");
   if (rc || splitk == 1) return rc;
   const int n_out = a.epilogue == VGEN_EPI_GEGLU ? a.N / 2 : a.N;
@@ -506,10 +523,18 @@ int launch(const vgen_tapgemm_args& a, hipStream_t stream) {
 
 template <typename T>
 int dispatch(const vgen_tapgemm_args& a, hipStream_t s) {
-  switch (make_plan(a).bn) {
-    case 128: return launch<T, 128>(a, s);
-    case 160: return launch<T, 160>(a, s);
-    default: return launch<T, 64>(a, s);
+  const Plan pl = make_plan(a);
+  if (pl.bm == 256) {
+    switch (pl.bn) {
+      case 128: return launch<T, 256, 128, 3>(a, pl.splitk, s);
+      case 160: return launch<T, 256, 160, 3>(a, pl.splitk, s);
+      default: return launch<T, 256, 64, 3>(a, pl.splitk, s);
+    }
+  }
+  switch (pl.bn) {
+    case 128: return launch<T, 128, 128, 2>(a, pl.splitk, s);
+    case 160: return launch<T, 128, 160, 2>(a, pl.splitk, s);
+    default: return launch<T, 128, 64, 2>(a, pl.splitk, s);
   }
 }
 
