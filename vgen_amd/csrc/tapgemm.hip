@@ -34,6 +34,7 @@
 //     + fp32 residual, optional GEGLU gate, fp32 or 16-bit store.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -257,7 +258,8 @@ __global__ __launch_bounds__(BM * 2) void tapgemm_kernel(const vgen_tapgemm_args
   // added up (ablation: 142 us compute-only + 116 us DMA-only - 41 us fixed = 207 us measured at
   // 4096^3).  Spread one piece per MFMA group, the partner wave on the SIMD keeps the matrix pipe
   // busy while this wave waits on the address path.
-  auto compute = [&](int stage, bool prefetch, int stage_pf) {
+  auto compute = [&](int stage, auto prefetch_tag, int stage_pf) {
+    constexpr bool prefetch = decltype(prefetch_tag)::value;   // compile-time: branch-free K-step body
     const unsigned char* a = smem + stage * STAGE_BYTES + wm * WTM * ROW_BYTES + rd_row;
     const unsigned char* b = smem + stage * STAGE_BYTES + BM * ROW_BYTES + wn * WTN * ROW_BYTES + rd_row;
     u32x4 wf[2][NF], xf[2][MF];
@@ -307,7 +309,10 @@ __global__ __launch_bounds__(BM * 2) void tapgemm_kernel(const vgen_tapgemm_args
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    compute(st_c, it + AHEAD < nk, st_l);
+    // two straight-line bodies (with / without prefetch) instead of a per-piece branch: hipcc can
+    // then count lgkmcnt for the fragment reads instead of draining all 16 before the first MFMA
+    if (it + AHEAD < nk) compute(st_c, std::true_type{}, st_l);
+    else compute(st_c, std::false_type{}, st_l);
     st_c = st_c == STAGES - 1 ? 0 : st_c + 1;
     st_l = st_l == STAGES - 1 ? 0 : st_l + 1;
   }
