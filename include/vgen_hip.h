@@ -245,6 +245,27 @@ int vgen_cfg_ddim_step(const float* xt, const float* y, const float* u, const fl
 int vgen_gaussian_sample(const float* moments, const float* noise, int64_t nimg, int32_t zc,
                          int64_t HW, float scale, float* z, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * GaussianDiffusion (sigma-parametrised VP diffusion) pieces, tools/modules/diffusions/
+ * diffusion_gauss.py:163-247 (denoise) and :85-142 (sample_dpmpp_2m_sde).
+ *
+ * vgen_cfg_stats: out = use_guide ? u + guide*(y - u) : y, plus per-sample partial sums of
+ *   y, y^2, out, out^2 in `ws` (fp64; vgen_cfg_stats_ws_bytes(B) bytes) for guide_rescale.
+ * vgen_gauss_x0 : optional guide_rescale (rescale < 0 disables; arXiv:2305.08891, :212-218)
+ *   out *= rescale * std(y)/(std(out)+1e-12) + (1-rescale), then
+ *   x0 = (xt - sigma*out)/alpha (pred_type 0 'eps') | alpha*xt - sigma*out (1 'v') | out (2 'x0'),
+ *   eps = (xt - alpha*x0)/sigma (optional).  coef = [B][2] fp32 (alpha, sigma).
+ * vgen_lincomb4 : out = ca*a + cb*b + cc*c + cd*d (NULL operands skipped, fp32, no contraction):
+ *   the exponential-integrator / midpoint-correction / noise-injection update of DPM-Solver++(2M).
+ */
+size_t vgen_cfg_stats_ws_bytes(int64_t B);
+int vgen_cfg_stats(const float* y, const float* u, float guide, int32_t use_guide, int64_t B,
+                   int64_t per_b, float* out, void* ws, size_t ws_bytes, void* stream);
+int vgen_gauss_x0(const float* xt, const float* out, const void* ws, float rescale, const float* coef,
+                  int32_t pred_type, int64_t B, int64_t per_b, float* x0, float* eps, void* stream);
+int vgen_lincomb4(const float* a, const float* b, const float* c, const float* d, float ca, float cb,
+                  float cc, float cd, float* out, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -178,6 +178,30 @@ class EmuBackend:
             r = r + c[6] * c[5] * noise
         return r, (x0.clone() if want_x0 else None)
 
+    def gauss_denoise(self, xt, y, u, guide, rescale, coef, pred_type, want_eps):
+        shape = (xt.shape[0],) + (1,) * (xt.ndim - 1)
+        alpha, sigma = coef[:, 0].view(shape), coef[:, 1].view(shape)
+        out = y if u is None else u + torch.tensor(guide, dtype=torch.float32) * (y - u)
+        if rescale is not None:
+            ratio = (y.flatten(1).std(dim=1) / (out.flatten(1).std(dim=1) + 1e-12)).view(shape)
+            out = out * (rescale * ratio + (1 - rescale) * 1.0)
+        if pred_type == 2:
+            x0 = out
+        elif pred_type == 0:
+            x0 = (xt - sigma * out) / alpha
+        else:
+            x0 = alpha * xt - sigma * out
+        eps = (xt - alpha * x0) / sigma if want_eps else None
+        return x0, eps
+
+    def lincomb4(self, a, b, c, d, ca, cb, cc, cd):
+        f = lambda v: torch.tensor(v, dtype=torch.float32)
+        r = f(ca) * a
+        for t, cf in ((b, cb), (c, cc), (d, cd)):
+            if t is not None:
+                r = r + f(cf) * t
+        return r
+
     def gaussian_sample(self, moments, noise, nimg, zc, HW, scale):
         m = moments.view(nimg, HW, 2 * zc)
         mean = m[..., :zc].permute(0, 2, 1).reshape(noise.shape)

@@ -91,6 +91,29 @@ def main():
                     tables=dict(alphas_cumprod=diff.alphas_cumprod, sqrt_recipm1=diff.sqrt_recipm1_alphas_cumprod)),
                os.path.join(GOLD, "ddim.pt"))
 
+    # ---- GaussianDiffusion (sr600 forward/reverse diffusions, sr600_infer.yaml) ----------------------
+    G = R["diffusion_gauss"]
+    sig_fwd = rs.sigma_schedule("logsnr_cosine_interp", 1000, zero_terminal_snr=True, scale_min=2.0,
+                                scale_max=4.0, logsnr_min=-15.0, logsnr_max=15.0)
+    sig_rev = rs.sigma_schedule("cosine", 1000, zero_terminal_snr=True, cosine_s=0.008)
+    gm = lambda x, t=None, y=None, **k: dummy_model(x, t, y=y)
+    fwd = G.GaussianDiffusion(sigmas=sig_fwd, prediction_type="v")
+    rev = G.GaussianDiffusion(sigmas=sig_rev, prediction_type="v")
+    gg = torch.Generator("cpu").manual_seed(21)
+    gnoise = torch.randn(2, 4, 4, 8, 8, generator=gg)
+    gkw = [dict(y=torch.randn(2, 7, 16, generator=gg)), dict(y=torch.randn(2, 7, 16, generator=gg))]
+    torch.manual_seed(1)
+    g_s0 = fwd.sample(noise=gnoise.clone(), model=gm, model_kwargs=gkw, guide_scale=9.0, guide_rescale=0.3,
+                      solver="dpmpp_2m_sde", steps=30, t_max=699, t_min=0, discretization="trailing", eta=0.0)
+    g_inv = rev.ddim_reverse_sample_loop(gnoise.clone(), gm, gkw[1], guide_scale=None, ddim_timesteps=30,
+                                         reverse_steps=700)
+    gt = torch.tensor([500, 20])
+    g_den = fwd.denoise(gnoise, gt, None, gm, gkw, guide_scale=7.5, guide_rescale=0.3)
+    torch.save(dict(sig_fwd=sig_fwd, sig_rev=sig_rev, noise=gnoise, kw=gkw, sample_eta0=g_s0, inv30=g_inv,
+                    den_t=gt, den=[v.contiguous() for v in g_den],
+                    sigma_to_t=fwd._sigma_to_t(torch.tensor(3.7)),
+                    t_to_sigma=fwd._t_to_sigma(torch.tensor([10.5, 699.0]))), os.path.join(GOLD, "gauss.pt"))
+
     # ---- tiny UNet ---------------------------------------------------------------------------
     ref = R["MODEL"].build(dict(type="UNetSD_T2VBase", **UNET_TINY)).eval()
     shapes = torch_ref.shapes_of(ref)

@@ -62,10 +62,27 @@ def load():
         spec.loader.exec_module(mod)
         return mod
 
+    # torchsde (==0.2.6 in the reference's requirements.txt) is not installed: a deterministic stand-in
+    # for BrownianTree so that sample_dpmpp_2m_sde can run; increments are N(0, |tb - ta|) drawn from a
+    # generator keyed on (entropy, ta, tb).  Parity of the true torchsde noise is unpinned.
+    import torch as _torch
+    ts = types.ModuleType("torchsde")
+
+    class BrownianTree:
+        def __init__(self, t0, w0, t1, entropy=None, **kw):
+            self.shape, self.entropy = w0.shape, int(entropy or 0)
+
+        def __call__(self, ta, tb):
+            key = (self.entropy * 1000003 + int(float(ta) * 1e6) * 7919 + int(float(tb) * 1e6)) % (2 ** 62)
+            g = _torch.Generator("cpu").manual_seed(key)
+            return _torch.randn(self.shape, generator=g) * (float(tb) - float(ta)) ** 0.5
+
+    ts.BrownianTree = BrownianTree
+    sys.modules["torchsde"] = ts
     mods = {}
     for n in ("tools.modules.unet.util", "tools.modules.unet.unet_t2v", "tools.modules.autoencoder",
               "tools.modules.diffusions.schedules", "tools.modules.diffusions.losses",
-              "tools.modules.diffusions.diffusion_ddim"):
+              "tools.modules.diffusions.diffusion_ddim", "tools.modules.diffusions.diffusion_gauss"):
         mods[n.rsplit(".", 1)[-1]] = _load(n)
     from utils.registry_class import AUTO_ENCODER, DIFFUSION, MODEL
     _loaded.update(mods)

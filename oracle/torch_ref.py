@@ -368,3 +368,115 @@ def ddim_sample_loop(betas64, noise, model, model_kwargs, guide_scale, ddim_step
         xt, _ = ddim_step(tabs, xt, t, y_out, u_out, guide_scale, mean_type, T // ddim_steps, eta,
                           torch.randn_like(xt) if eta else None, T)
     return xt
+
+
+# ------------------------------------------------------------------------------------------
+# GaussianDiffusion: denoise + DPM-Solver++(2M) SDE + DDIM inversion (fp32)
+# ------------------------------------------------------------------------------------------
+
+
+def gauss_tables(sigmas64):
+    # GaussianDiffusion.__init__, diffusions/diffusion_gauss.py:147-152
+    return dict(sigmas=sigmas64.float(), alphas=torch.sqrt(1 - sigmas64 ** 2).float())
+
+
+def gauss_x0_eps(tabs, xt, t, y_out, u_out, guide_scale, guide_rescale, prediction_type):
+    """GaussianDiffusion.denoise, diffusion_gauss.py:182-183 (tables), :198-218 (CFG + guide_rescale),
+    :220-243 (x0, eps)."""
+    shape = (xt.size(0),) + (1,) * (xt.ndim - 1)
+    sigmas, alphas = tabs["sigmas"][t].view(shape), tabs["alphas"][t].view(shape)
+    out = y_out
+    if u_out is not None:
+        out = u_out + guide_scale * (y_out - u_out)
+        if guide_rescale is not None:
+            ratio = (y_out.flatten(1).std(dim=1) / (out.flatten(1).std(dim=1) + 1e-12)).view(shape)
+            out = out * (guide_rescale * ratio + (1 - guide_rescale) * 1.0)
+    if prediction_type == "x0":
+        x0 = out
+    elif prediction_type == "eps":
+        x0 = (xt - sigmas * out) / alphas
+    else:
+        x0 = alphas * xt - sigmas * out
+    return x0, (xt - alphas * x0) / sigmas
+
+
+def gauss_log_sigmas(tabs):
+    return torch.sqrt(tabs["sigmas"] ** 2 / (1 - tabs["sigmas"] ** 2)).log()
+
+
+def gauss_sigma_to_t(tabs, sigma):
+    # GaussianDiffusion._sigma_to_t, diffusion_gauss.py:436-456
+    ls = gauss_log_sigmas(tabs).to(sigma)
+    log_sigma = sigma.log()
+    dists = log_sigma - ls[:, None]
+    low_idx = dists.ge(0).cumsum(dim=0).argmax(dim=0).clamp(max=ls.shape[0] - 2)
+    high_idx = low_idx + 1
+    low, high = ls[low_idx], ls[high_idx]
+    w = ((low - log_sigma) / (low - high)).clamp(0, 1)
+    t = ((1 - w) * low_idx + w * high_idx).view(sigma.shape)
+    return t.unsqueeze(0) if t.ndim == 0 else t
+
+
+def gauss_t_to_sigma(tabs, t):
+    # GaussianDiffusion._t_to_sigma, diffusion_gauss.py:458-464
+    t = t.float()
+    low_idx, high_idx, w = t.floor().long(), t.ceil().long(), t.frac()
+    ls = gauss_log_sigmas(tabs).to(t)
+    log_sigma = (1 - w) * ls[low_idx] + w * ls[high_idx]
+    log_sigma[torch.isnan(log_sigma) | torch.isinf(log_sigma)] = float("inf")
+    return log_sigma.exp()
+
+
+def gauss_trailing_sigmas(tabs, steps, t_max, t_min=0):
+    # GaussianDiffusion.sample with discretization='trailing', discard_penultimate_step=True
+    # (diffusion_gauss.py:318-364): steps+1 trailing timesteps, sigma(t), append 0, drop penultimate
+    steps = steps + 1
+    ts = torch.arange(t_max, t_min - 1, -((t_max - t_min + 1) / steps)).clamp_(t_min, t_max)
+    sig = gauss_t_to_sigma(tabs, torch.as_tensor(ts, dtype=torch.float32))
+    sig = torch.cat([sig, sig.new_zeros([1])])
+    return torch.cat([sig[:-2], sig[-1:]])
+
+
+def dpmpp_2m_sde(tabs, noise, model, model_kwargs, sigmas, guide_scale, guide_rescale, prediction_type,
+                 eta=1.0, s_noise=1.0, noise_fn=None):
+    """sample_dpmpp_2m_sde (midpoint), diffusion_gauss.py:85-142, with model_fn of :303-316 inlined;
+    `noise_fn(sigma, sigma_next)` supplies the (third-party torchsde) Brownian increment / sqrt(dt)."""
+    x = noise * sigmas[0]
+    old_denoised, h_last = None, None
+    for i in range(len(sigmas) - 1):
+        c_in = 1 / (sigmas[i] ** 2 + 1.) ** 0.5
+        t = gauss_sigma_to_t(tabs, sigmas[i]).repeat(len(x)).round().long()
+        xin = x * c_in
+        y_out = model(xin, t=t, **model_kwargs[0])
+        u_out = model(xin, t=t, **model_kwargs[1])
+        denoised, _ = gauss_x0_eps(tabs, xin, t, y_out, u_out, guide_scale, guide_rescale, prediction_type)
+        if sigmas[i + 1] == 0:
+            x = denoised
+            h = None
+        else:
+            tt, s = -sigmas[i].log(), -sigmas[i + 1].log()
+            h = s - tt
+            eta_h = eta * h
+            x = sigmas[i + 1] / sigmas[i] * (-eta_h).exp() * x + (-h - eta_h).expm1().neg() * denoised
+            if old_denoised is not None:
+                r = h_last / h
+                x = x + 0.5 * (-h - eta_h).expm1().neg() * (1 / r) * (denoised - old_denoised)
+            if eta and noise_fn is not None:
+                x = x + noise_fn(sigmas[i], sigmas[i + 1]) * sigmas[i + 1] * (-2 * eta_h).expm1().neg().sqrt() * s_noise
+        old_denoised, h_last = denoised, h
+    return x
+
+
+def gauss_ddim_reverse_loop(tabs, x0, model, model_kwargs, prediction_type, ddim_timesteps, reverse_steps):
+    # GaussianDiffusion.ddim_reverse_sample(_loop), diffusion_gauss.py:375-434 (no guidance)
+    xt = x0
+    stride = reverse_steps // ddim_timesteps
+    for step in torch.arange(0, reverse_steps, stride):
+        t = torch.full((x0.size(0),), int(step), dtype=torch.long)
+        out = model(xt, t=t, **model_kwargs)
+        px0, eps = gauss_x0_eps(tabs, xt, t, out, None, None, None, prediction_type)
+        s = (t + stride).clamp(0, reverse_steps - 1)
+        shape = (xt.size(0),) + (1,) * (xt.ndim - 1)
+        a_s = tabs["alphas"][s].view(shape)
+        xt = a_s * px0 + torch.sqrt(1 - a_s ** 2) * eps
+    return xt

@@ -1,0 +1,168 @@
+"""GaussianDiffusion / DPM-Solver++(2M) SDE / DDIM inversion: oracle and host
+logic against reference-generated fixtures (tests/golden/gauss.pt) and the live reference."""
+import pytest
+import torch
+
+from conftest import gold, rel_l2
+from oracle import torch_ref
+from oracle.make_golden import dummy_model
+from vgen_amd import schedules
+
+
+def _gm(x, t=None, y=None, **k):
+    return dummy_model(x, t, y=y)
+
+
+def _mine():
+    from vgen_amd.diffusion_gauss import GaussianDiffusion
+    fwd = GaussianDiffusion(schedules.sigma_schedule("logsnr_cosine_interp", 1000, zero_terminal_snr=True,
+                                                     scale_min=2.0, scale_max=4.0, logsnr_min=-15.0,
+                                                     logsnr_max=15.0), prediction_type="v")
+    rev = GaussianDiffusion(schedules.sigma_schedule("cosine", 1000, zero_terminal_snr=True, cosine_s=0.008),
+                            prediction_type="v")
+    return fwd, rev
+
+
+def test_oracle_gauss_vs_golden():
+    g = gold("gauss.pt")
+    tabs = torch_ref.gauss_tables(g["sig_fwd"])
+    sig = torch_ref.gauss_trailing_sigmas(tabs, 30, 699)
+    out = torch_ref.dpmpp_2m_sde(tabs, g["noise"].clone(), _gm, g["kw"], sig, 9.0, 0.3, "v", eta=0.0)
+    assert rel_l2(out, g["sample_eta0"]) < 2e-6
+    rt = torch_ref.gauss_tables(g["sig_rev"])
+    inv = torch_ref.gauss_ddim_reverse_loop(rt, g["noise"].clone(), _gm, g["kw"][1], "v", 30, 700)
+    assert rel_l2(inv, g["inv30"]) < 2e-6
+    assert torch.equal(torch_ref.gauss_sigma_to_t(tabs, torch.tensor(3.7)), g["sigma_to_t"])
+    assert torch.equal(torch_ref.gauss_t_to_sigma(tabs, torch.tensor([10.5, 699.0])), g["t_to_sigma"])
+    y, u = _gm(g["noise"], g["den_t"], **g["kw"][0]), _gm(g["noise"], g["den_t"], **g["kw"][1])
+    x0, eps = torch_ref.gauss_x0_eps(tabs, g["noise"], g["den_t"], y, u, 7.5, 0.3, "v")
+    assert rel_l2(x0, g["den"][3]) < 1e-6 and rel_l2(eps, g["den"][4]) < 1e-6
+
+
+def test_gauss_host_logic_vs_golden(emu_backend):
+    g = gold("gauss.pt")
+    fwd, rev = _mine()
+    assert torch.equal(fwd.sigmas, g["sig_fwd"].float()) and torch.equal(rev.sigmas, g["sig_rev"].float())
+    out = fwd.sample(noise=g["noise"].clone(), model=_gm, model_kwargs=g["kw"], guide_scale=9.0, guide_rescale=0.3,
+                     solver="dpmpp_2m_sde", steps=30, t_max=699, t_min=0, discretization="trailing", eta=0.0)
+    assert rel_l2(out, g["sample_eta0"]) < 2e-6
+    inv = rev.ddim_reverse_sample_loop(g["noise"].clone(), _gm, g["kw"][1], guide_scale=None, ddim_timesteps=30,
+                                       reverse_steps=700)
+    assert rel_l2(inv, g["inv30"]) < 2e-6
+    den = fwd.denoise(g["noise"], g["den_t"], None, _gm, g["kw"], guide_scale=7.5, guide_rescale=0.3)
+    for a, b in zip(den, g["den"]):
+        assert rel_l2(a, b) < 2e-6
+    assert torch.equal(fwd._sigma_to_t(torch.tensor(3.7)), g["sigma_to_t"])
+    assert torch.equal(fwd._t_to_sigma(torch.tensor([10.5, 699.0])), g["t_to_sigma"])
+
+
+def test_gauss_call_pattern(emu_backend):
+    """30 trailing steps from t_max 699: 60 model calls at t = 699, 676, 654, ... (SURVEY §3.4 probe)."""
+    fwd, rev = _mine()
+    g = gold("gauss.pt")
+    calls = []
+
+    def model(x, t=None, y=None, **k):
+        calls.append(int(t[0]))
+        return dummy_model(x, t, y=y)
+
+    fwd.sample(noise=g["noise"].clone(), model=model, model_kwargs=g["kw"], guide_scale=9.0, guide_rescale=0.3,
+               solver="dpmpp_2m_sde", steps=30, t_max=699, t_min=0, discretization="trailing", eta=0.0)
+    assert len(calls) == 60 and calls[0] == calls[1] == 699 and calls[2] == 676 and calls[4] == 654
+    calls.clear()
+    rev.ddim_reverse_sample_loop(g["noise"].clone(), model, g["kw"][1], guide_scale=None, ddim_timesteps=30,
+                                 reverse_steps=700)
+    assert calls == list(range(0, 700, 23))[:31] and len(calls) == 31
+
+
+def test_sde_noise_fallback_is_seeded_and_unit_variance(emu_backend):
+    from vgen_amd.diffusion_gauss import IntervalNoise
+    fwd, _ = _mine()
+    fwd.noise_sampler_cls = IntervalNoise
+    g = gold("gauss.pt")
+    kw = dict(noise=g["noise"].clone(), model=_gm, model_kwargs=g["kw"], guide_scale=9.0, solver="dpmpp_2m_sde",
+              steps=8, t_max=699, discretization="trailing", eta=1.0)
+    a, b, c = fwd.sample(seed=5, **kw), fwd.sample(seed=5, **kw), fwd.sample(seed=6, **kw)
+    assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all()
+    n = IntervalNoise(torch.zeros(4, 4, 16, 16), 0.1, 1.0, seed=1)(1.0, 0.5)
+    assert abs(float(n.std()) - 1.0) < 0.05
+
+
+def test_ddimsr_registry_build():
+    import vgen_amd
+    from vgen_amd.registry import Registry
+    regs = vgen_amd.install({"MODEL": Registry("MODEL"), "AUTO_ENCODER": Registry("AUTO_ENCODER"),
+                             "DIFFUSION": Registry("DIFFUSION")})
+
+    class AttrDict(dict):            # EasyDict-like: the reference reads `.schedule` etc. by attribute
+        def __getattr__(self, k):
+            try:
+                return self[k]
+            except KeyError:
+                raise AttributeError(k)
+
+    d = regs["DIFFUSION"].build(dict(
+        type="DiffusionDDIMSR",
+        reverse_diffusion=AttrDict(schedule="cosine", mean_type="v",
+                                   schedule_param=dict(num_timesteps=1000, cosine_s=0.008, zero_terminal_snr=True)),
+        forward_diffusion=AttrDict(schedule="logsnr_cosine_interp", mean_type="v",
+                                   schedule_param=dict(num_timesteps=1000, zero_terminal_snr=True, scale_min=2.0,
+                                                       scale_max=4.0, logsnr_min=-15.0, logsnr_max=15.0))))
+    g = gold("gauss.pt")
+    assert torch.equal(d.forward_diffusion.sigmas, g["sig_fwd"].float())
+    assert torch.equal(d.reverse_diffusion.sigmas, g["sig_rev"].float())
+
+
+@pytest.mark.reference
+def test_gauss_vs_live_reference_including_sde_noise(emu_backend):
+    """Full stochastic update (eta = 1) with the SAME deterministic Brownian stand-in on both sides."""
+    from oracle import ref_import
+    R = ref_import.load()
+    G = R["diffusion_gauss"]
+    fwd, _ = _mine()
+    fwd.noise_sampler_cls = G.BrownianTreeNoiseSampler
+    ref = G.GaussianDiffusion(sigmas=R["schedules"].sigma_schedule(
+        "logsnr_cosine_interp", 1000, zero_terminal_snr=True, scale_min=2.0, scale_max=4.0, logsnr_min=-15.0,
+        logsnr_max=15.0), prediction_type="v")
+    g = gold("gauss.pt")
+    kw = dict(model=_gm, model_kwargs=g["kw"], guide_scale=9.0, guide_rescale=0.3, solver="dpmpp_2m_sde", steps=12,
+              t_max=699, t_min=0, discretization="trailing", eta=1.0)
+    torch.manual_seed(4)
+    a = ref.sample(noise=g["noise"].clone(), **kw)
+    torch.manual_seed(4)
+    b = fwd.sample(noise=g["noise"].clone(), **kw)
+    assert rel_l2(b, a) < 2e-6
+
+
+# ---- GPU: the three kernels vs the emulator, and the sampler on the device ----------------------------
+@pytest.mark.gpu
+def test_gauss_kernels_gpu(hip_backend):
+    from oracle.abi_emulator import EmuBackend
+    emu = EmuBackend()
+    g = torch.Generator().manual_seed(0)
+    xt, y, u = (torch.randn(3, 4, 4, 16, 8, generator=g) for _ in range(3))
+    coef = torch.tensor([[0.8, 0.6], [0.3, 0.954], [0.999, 0.04]])
+    for pred in (0, 1, 2):
+        for resc in (None, 0.3):
+            a = emu.gauss_denoise(xt, y, u, 7.5, resc, coef, pred, True)
+            b = hip_backend.gauss_denoise(xt.cuda(), y.cuda(), u.cuda(), 7.5, resc, coef.cuda(), pred, True)
+            assert rel_l2(b[0], a[0]) < 2e-6 and rel_l2(b[1], a[1]) < 2e-5, (pred, resc)
+    a = emu.gauss_denoise(xt, y, None, 0.0, None, coef, 1, False)
+    b = hip_backend.gauss_denoise(xt.cuda(), y.cuda(), None, 0.0, None, coef.cuda(), 1, False)
+    assert torch.equal(b[0].cpu(), a[0]) and b[1] is None
+    r = emu.lincomb4(xt, y, u, None, 0.3, -1.7, 0.25, 0)
+    rg = hip_backend.lincomb4(xt.cuda(), y.cuda(), u.cuda(), None, 0.3, -1.7, 0.25, 0)
+    assert torch.equal(rg.cpu(), r)
+
+
+@pytest.mark.gpu
+def test_gauss_sampler_on_device_vs_golden(hip_backend):
+    g = gold("gauss.pt")
+    fwd, rev = _mine()
+    kw = [dict(y=k["y"].cuda()) for k in g["kw"]]
+    out = fwd.sample(noise=g["noise"].cuda(), model=_gm, model_kwargs=kw, guide_scale=9.0, guide_rescale=0.3,
+                     solver="dpmpp_2m_sde", steps=30, t_max=699, t_min=0, discretization="trailing", eta=0.0)
+    assert rel_l2(out, g["sample_eta0"]) < 2e-5
+    inv = rev.ddim_reverse_sample_loop(g["noise"].cuda(), _gm, kw[1], guide_scale=None, ddim_timesteps=30,
+                                       reverse_steps=700)
+    assert rel_l2(inv, g["inv30"]) < 2e-5

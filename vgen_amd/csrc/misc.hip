@@ -260,3 +260,165 @@ extern "C" int vgen_gaussian_sample(const float* moments, const float* noise, in
                      (hipStream_t)stream, moments, noise, zc, HW, total, scale, z);
   return vgen_check_launch("gaussian_sample");
 }
+
+// ---------------------------------------------------------------------------------------------
+// GaussianDiffusion.denoise / DPM-Solver++(2M) SDE pieces (tools/modules/diffusions/
+// diffusion_gauss.py:163-247, 85-142).
+namespace {
+
+constexpr int CS_THREADS = 256;
+
+// out = u + g*(y - u) and per-(batch, block) partial sums of y, y^2, out, out^2 (guide_rescale needs
+// the per-sample std of both, diffusion_gauss.py:212-218).  grid = (nblk, B).
+__global__ __launch_bounds__(CS_THREADS) void cfg_stats_kernel(const float* __restrict__ y,
+                                                               const float* __restrict__ u, float guide,
+                                                               int use_guide, int64_t per_b,
+                                                               float* __restrict__ out,
+                                                               double* __restrict__ partial) {
+#pragma clang fp contract(off)
+  __shared__ double red[4][CS_THREADS / 64];
+  const int64_t b = blockIdx.y;
+  const int nblk = gridDim.x;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  for (int64_t i = (int64_t)blockIdx.x * CS_THREADS + threadIdx.x; i < per_b; i += (int64_t)nblk * CS_THREADS) {
+    const float yy = y[b * per_b + i];
+    float o = yy;
+    if (use_guide) {
+      const float uu = u[b * per_b + i];
+      const float d = yy - uu;
+      const float sc = guide * d;
+      o = uu + sc;
+    }
+    out[b * per_b + i] = o;
+    s0 += yy;
+    s1 += (double)yy * yy;
+    s2 += o;
+    s3 += (double)o * o;
+  }
+  double v[4] = {s0, s1, s2, s3};
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    double t = 0;
+    for (int w = 0; w < CS_THREADS / 64; ++w) t += red[threadIdx.x][w];
+    partial[(b * nblk + blockIdx.x) * 4 + threadIdx.x] = t;
+  }
+}
+
+// rescale (optional) + x0 / eps from the combined model output (diffusion_gauss.py:212-247):
+//   out *= rescale * std(y)/(std(out)+1e-12) + (1 - rescale)      [unbiased std over the sample]
+//   x0 = out | (xt - sigma*out)/alpha | alpha*xt - sigma*out ;  eps = (xt - alpha*x0)/sigma
+__global__ __launch_bounds__(CS_THREADS) void gauss_x0_kernel(const float* __restrict__ xt,
+                                                              const float* __restrict__ outc,
+                                                              const double* __restrict__ partial,
+                                                              int nblk, float rescale,
+                                                              const float* __restrict__ coef,
+                                                              int pred_type, int64_t per_b,
+                                                              float* __restrict__ x0o,
+                                                              float* __restrict__ epso) {
+#pragma clang fp contract(off)
+  __shared__ float s_mul;
+  const int64_t b = blockIdx.y;
+  if (threadIdx.x == 0) {
+    float mul = 1.0f;
+    if (rescale >= 0.f) {
+      double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+      for (int k = 0; k < nblk; ++k) {
+        const double* p = partial + (b * nblk + k) * 4;
+        a0 += p[0];
+        a1 += p[1];
+        a2 += p[2];
+        a3 += p[3];
+      }
+      const double n = (double)per_b;
+      const double vy = (a1 - a0 * a0 / n) / (n - 1.0), vo = (a3 - a2 * a2 / n) / (n - 1.0);
+      const float sy = (float)sqrt(vy > 0 ? vy : 0.0), so = (float)sqrt(vo > 0 ? vo : 0.0);
+      const float ratio = sy / (so + 1e-12f);
+      mul = rescale * ratio + (1.0f - rescale) * 1.0f;
+    }
+    s_mul = mul;
+  }
+  __syncthreads();
+  const float mul = s_mul;
+  const float alpha = coef[b * 2 + 0], sigma = coef[b * 2 + 1];
+  for (int64_t i = (int64_t)blockIdx.x * CS_THREADS + threadIdx.x; i < per_b;
+       i += (int64_t)gridDim.x * CS_THREADS) {
+    const float x = xt[b * per_b + i];
+    float o = outc[b * per_b + i];
+    if (rescale >= 0.f) o = o * mul;
+    float x0;
+    if (pred_type == 2) {
+      x0 = o;
+    } else if (pred_type == 0) {
+      const float t0 = sigma * o;
+      const float t1 = x - t0;
+      x0 = t1 / alpha;
+    } else {
+      const float t0 = alpha * x;
+      const float t1 = sigma * o;
+      x0 = t0 - t1;
+    }
+    x0o[b * per_b + i] = x0;
+    if (epso) {
+      const float t2 = alpha * x0;
+      const float t3 = x - t2;
+      epso[b * per_b + i] = t3 / sigma;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void lincomb4_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                       const float* __restrict__ c, const float* __restrict__ d,
+                                                       float ca, float cb, float cc, float cd,
+                                                       float* __restrict__ out, int64_t n) {
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float r = ca * a[i];
+  if (b) r = r + cb * b[i];
+  if (c) r = r + cc * c[i];
+  if (d) r = r + cd * d[i];
+  out[i] = r;
+}
+
+}  // namespace
+
+extern "C" size_t vgen_cfg_stats_ws_bytes(int64_t B) { return (size_t)B * 64 * 4 * sizeof(double); }
+
+extern "C" int vgen_cfg_stats(const float* y, const float* u, float guide, int32_t use_guide, int64_t B,
+                              int64_t per_b, float* out, void* ws, size_t ws_bytes, void* stream) {
+  VGEN_REQUIRE(B > 0 && per_b > 0 && B <= 65535, "cfg_stats: sizes");
+  VGEN_REQUIRE(!use_guide || u != nullptr, "cfg_stats: guidance needs u");
+  if (ws_bytes < vgen_cfg_stats_ws_bytes(B)) {
+    vgen_set_error("cfg_stats: workspace too small");
+    return VGEN_E_WORKSPACE;
+  }
+  hipLaunchKernelGGL(cfg_stats_kernel, dim3(64, (unsigned)B), dim3(CS_THREADS), 0, (hipStream_t)stream, y, u,
+                     guide, use_guide, per_b, out, (double*)ws);
+  return vgen_check_launch("cfg_stats");
+}
+
+extern "C" int vgen_gauss_x0(const float* xt, const float* out, const void* ws, float rescale, const float* coef,
+                             int32_t pred_type, int64_t B, int64_t per_b, float* x0, float* eps, void* stream) {
+  VGEN_REQUIRE(B > 0 && per_b > 1 && B <= 65535 && pred_type >= 0 && pred_type <= 2, "gauss_x0: args");
+  VGEN_REQUIRE(rescale < 0.f || ws != nullptr, "gauss_x0: rescale needs the cfg_stats workspace");
+  hipLaunchKernelGGL(gauss_x0_kernel, dim3(64, (unsigned)B), dim3(CS_THREADS), 0, (hipStream_t)stream, xt, out,
+                     (const double*)ws, 64, rescale, coef, pred_type, per_b, x0, eps);
+  return vgen_check_launch("gauss_x0");
+}
+
+extern "C" int vgen_lincomb4(const float* a, const float* b, const float* c, const float* d, float ca, float cb,
+                             float cc, float cd, float* out, int64_t n, void* stream) {
+  VGEN_REQUIRE(a != nullptr && out != nullptr, "lincomb4: a/out null");
+  if (n <= 0) return 0;
+  const int64_t grid = (n + 255) / 256;
+  VGEN_REQUIRE(grid < (1LL << 31), "lincomb4: too large");
+  hipLaunchKernelGGL(lincomb4_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, a, b, c, d, ca, cb,
+                     cc, cd, out, n);
+  return vgen_check_launch("lincomb4");
+}

@@ -264,6 +264,35 @@ class HipBackend:
         _lib.check(rc, "vgen_cfg_ddim_step")
         return out, x0
 
+    def gauss_denoise(self, xt, y, u, guide, rescale, coef, pred_type, want_eps):
+        """CFG (+guide_rescale) + x0 (+eps) of GaussianDiffusion.denoise; all fp32 contiguous."""
+        for t in (xt, y, u, coef):
+            assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+        B = xt.shape[0]
+        per_b = xt.numel() // B
+        out = torch.empty_like(xt)
+        nbytes = self.lib.vgen_cfg_stats_ws_bytes(B)
+        ws = torch.empty(nbytes // 8, dtype=torch.float64, device=xt.device)
+        st = self._stream(xt)
+        rc = self.lib.vgen_cfg_stats(_ptr(y), _ptr(u), float(guide), int(u is not None), B, per_b, _ptr(out),
+                                     _ptr(ws), nbytes, st)
+        _lib.check(rc, "vgen_cfg_stats")
+        x0 = torch.empty_like(xt)
+        eps = torch.empty_like(xt) if want_eps else None
+        rc = self.lib.vgen_gauss_x0(_ptr(xt), _ptr(out), _ptr(ws), -1.0 if rescale is None else float(rescale),
+                                    _ptr(coef), int(pred_type), B, per_b, _ptr(x0), _ptr(eps), st)
+        _lib.check(rc, "vgen_gauss_x0")
+        return x0, eps
+
+    def lincomb4(self, a, b, c, d, ca, cb, cc, cd):
+        for t in (a, b, c, d):
+            assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+        out = torch.empty_like(a)
+        rc = self.lib.vgen_lincomb4(_ptr(a), _ptr(b), _ptr(c), _ptr(d), float(ca), float(cb), float(cc), float(cd),
+                                    _ptr(out), a.numel(), self._stream(a))
+        _lib.check(rc, "vgen_lincomb4")
+        return out
+
     def gaussian_sample(self, moments, noise, nimg, zc, HW, scale):
         assert moments.dtype == torch.float32 and moments.is_contiguous()
         assert noise.dtype == torch.float32 and noise.is_contiguous()

@@ -96,9 +96,11 @@ DIFFUSION = Registry("DIFFUSION")
 
 def _native_classes():
     from .diffusion import DiffusionDDIM
+    from .diffusion_gauss import DiffusionDDIMSR
     from .unet import UNetSD_T2VBase
     from .vae import AutoencoderKL
-    return {"MODEL": [UNetSD_T2VBase], "AUTO_ENCODER": [AutoencoderKL], "DIFFUSION": [DiffusionDDIM]}
+    return {"MODEL": [UNetSD_T2VBase], "AUTO_ENCODER": [AutoencoderKL],
+            "DIFFUSION": [DiffusionDDIM, DiffusionDDIMSR]}
 
 
 def install(registries=None, quiet=True):
