@@ -144,6 +144,8 @@ typedef struct vgen_tapgemm_args {
   int32_t epilogue;
   void* ws;        /* optional split-K workspace (fp32), see vgen_tapgemm_ws_bytes */
   size_t ws_bytes;
+  int32_t crop_t;  /* CONV3X3 with ups: rows cropped from the top AND bottom of the upsampled image
+                      before the conv (UpsampleSR600: x[..., 1:-1, :], util.py:801) */
 } vgen_tapgemm_args;
 
 /* Launches whose tile count cannot fill the 256 CUs (small M: the 4x7 / 8x14 UNet levels) are
@@ -258,6 +260,16 @@ int vgen_gaussian_sample(const float* moments, const float* noise, int64_t nimg,
  * vgen_lincomb4 : out = ca*a + cb*b + cc*c + cd*d (NULL operands skipped, fp32, no contraction):
  *   the exponential-integrator / midpoint-correction / noise-injection update of DPM-Solver++(2M).
  */
+/* FreeU-style skip filter of UNetSD_SR600 (unet_sr600.py:30-49, 276-287), on rows [nimg*H*W, C] fp32:
+ * Fourier_filter(x, threshold=1, scale) multiplies the 2x2 block of centred-spectrum bins
+ * {-1,0} x {-1,0} by `scale` and keeps the real part of the inverse FFT; being linear in 4 bins it is
+ * computed exactly as  y = x + (scale-1)/(H*W) * Re[sum_{u,v in {0,-1}} X[u,v] e^{2 pi i (u h/H + v w/W)}]
+ * from 7 weighted sums per (image, channel) — no FFT.  ws: 7*nimg*C floats. */
+int vgen_lowfreq_filter(const float* x, int64_t nimg, int32_t H, int32_t W, int32_t C, float scale,
+                        float* y, float* ws, size_t ws_bytes, void* stream);
+/* x[:, c0:c1] *= s in place on rows [M, C] fp32 (unet_sr600.py:278,284: backbone half-channel boost). */
+int vgen_scale_channels(float* x, int64_t M, int32_t C, int32_t c0, int32_t c1, float s, void* stream);
+
 size_t vgen_cfg_stats_ws_bytes(int64_t B);
 int vgen_cfg_stats(const float* y, const float* u, float guide, int32_t use_guide, int64_t B,
                    int64_t per_b, float* out, void* ws, size_t ws_bytes, void* stream);

@@ -53,12 +53,12 @@ class EmuBackend:
             hw = g.Ho * g.Wo
             img, rem = m // hw, m % hw
             oy, ox = rem // g.Wo, rem % g.Wo
-            Hv, Wv = g.Hi << g.ups, g.Wi << g.ups
+            Hv, Wv = (g.Hi << g.ups) - 2 * g.crop_t, g.Wi << g.ups
             for tap in range(9):
                 iy = oy * g.stride + tap // 3 - g.pad_t
                 ix = ox * g.stride + tap % 3 - g.pad_l
                 ok = (iy >= 0) & (iy < Hv) & (ix >= 0) & (ix < Wv)
-                r = img * g.Hi * g.Wi + (iy >> g.ups) * g.Wi + (ix >> g.ups)
+                r = img * g.Hi * g.Wi + ((iy + g.crop_t) >> g.ups) * g.Wi + (ix >> g.ups)
                 rows.append(torch.where(ok, r, torch.full_like(r, -1)))
         elif g.mode == L.TAP_TEMPORAL3:
             f = (m // g.S) % g.F
@@ -177,6 +177,24 @@ class EmuBackend:
         if noise is not None:
             r = r + c[6] * c[5] * noise
         return r, (x0.clone() if want_x0 else None)
+
+    def lowfreq_filter(self, x, nimg, H, W, scale):
+        # header formula, evaluated directly (independent of torch.fft)
+        C = x.shape[1]
+        v = x.view(nimg, H, W, C).double()
+        th = 2 * math.pi * torch.arange(H, dtype=torch.float64) / H
+        tw = 2 * math.pi * torch.arange(W, dtype=torch.float64) / W
+        acc = torch.zeros_like(v)
+        for u in (0, -1):
+            for w_ in (0, -1):
+                ph = (u * th)[:, None] + (w_ * tw)[None, :]                       # [H, W]
+                X = (v * torch.exp(-1j * ph)[None, :, :, None]).sum(dim=(1, 2))      # [nimg, C] complex
+                acc += (X[:, None, None, :] * torch.exp(1j * ph)[None, :, :, None]).real
+        return (v + (scale - 1.0) / (H * W) * acc).float().view(nimg * H * W, C)
+
+    def scale_channels(self, x, c0, c1, s):
+        x[:, c0:c1] *= s
+        return x
 
     def gauss_denoise(self, xt, y, u, guide, rescale, coef, pred_type, want_eps):
         shape = (xt.shape[0],) + (1,) * (xt.ndim - 1)

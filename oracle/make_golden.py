@@ -126,6 +126,27 @@ def main():
                os.path.join(GOLD, "unet_tiny.pt"))
     print("unet_tiny", tuple(out.shape), float(out.std()))
 
+    # ---- tiny UNetSD_SR600 ---------------------------------------------------------------------
+    SR_TINY = dict(UNET_TINY, dim_mult=[1, 2, 4, 4], use_scale_shift_norm=True, inpainting=True)
+    for k in ("use_fps_condition",):
+        SR_TINY.pop(k, None)
+    sr = R["MODEL"].build(dict(type="UNetSD_SR600", **SR_TINY)).eval()
+    srshapes = torch_ref.shapes_of(sr)
+    sr.load_state_dict(torch_ref.synth_state_dict(srshapes, seed=3), strict=True)
+    gsr = torch.Generator("cpu").manual_seed(9)
+    xsr = torch.randn(1, 4, 3, 18, 16, generator=gsr)       # 18 -> 10 -> 6 -> 4 rows: exercises pad (2,1) + crop
+    ysr = torch.randn(1, 77, 1024, generator=gsr)
+    tsr = torch.tensor([500])
+    _cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self           # Fourier_filter hard-codes .cuda() (unet_sr600.py:38)
+    try:
+        osr = sr(xsr.clone(), tsr, ysr)
+    finally:
+        torch.Tensor.cuda = _cuda
+    torch.save(dict(cfg=SR_TINY, seed=3, shapes=srshapes, x=xsr, t=tsr, y=ysr, out=osr),
+               os.path.join(GOLD, "unet_sr600_tiny.pt"))
+    print("unet_sr600_tiny", tuple(osr.shape), float(osr.std()))
+
     # ---- tiny VAE ------------------------------------------------------------------------------
     vae = R["AUTO_ENCODER"].build(dict(type="AutoencoderKL", ddconfig=VAE_TINY, embed_dim=4)).eval()
     vshapes = torch_ref.shapes_of(vae)

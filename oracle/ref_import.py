@@ -80,7 +80,8 @@ def load():
     ts.BrownianTree = BrownianTree
     sys.modules["torchsde"] = ts
     mods = {}
-    for n in ("tools.modules.unet.util", "tools.modules.unet.unet_t2v", "tools.modules.autoencoder",
+    for n in ("tools.modules.unet.util", "tools.modules.unet.unet_t2v", "tools.modules.unet.unet_sr600",
+              "tools.modules.autoencoder",
               "tools.modules.diffusions.schedules", "tools.modules.diffusions.losses",
               "tools.modules.diffusions.diffusion_ddim", "tools.modules.diffusions.diffusion_gauss"):
         mods[n.rsplit(".", 1)[-1]] = _load(n)

@@ -168,7 +168,23 @@ def _kind(sd, p):
     return None
 
 
-def unet_forward(sd, x, t, y, dim):
+def fourier_filter(x, threshold, scale):
+    # Fourier_filter, unet/unet_sr600.py:30-49 (the reference hard-codes .cuda() for the mask)
+    xf = torch.fft.fftshift(torch.fft.fftn(x.float(), dim=(-2, -1)), dim=(-2, -1))
+    B, C, H, W = xf.shape
+    mask = torch.ones((B, C, H, W))
+    crow, ccol = H // 2, W // 2
+    mask[..., crow - threshold:crow + threshold, ccol - threshold:ccol + threshold] = scale
+    return torch.fft.ifftn(torch.fft.ifftshift(xf * mask, dim=(-2, -1)), dim=(-2, -1)).real
+
+
+def unet_sr600_forward(sd, x, t, y, dim):
+    """UNetSD_SR600.forward, unet/unet_sr600.py:220-299: the t2v trunk with Downsample padding (2,1)
+    (:151), UpsampleSR600's crop (util.py:801) and the FreeU-style tweaks of decoder blocks 0/1."""
+    return unet_forward(sd, x, t, y, dim, down_padding=(2, 1), up_crop=1, freeu=((1.1, 0.6), (1.2, 0.4)))
+
+
+def unet_forward(sd, x, t, y, dim, down_padding=1, up_crop=0, freeu=None):
     """UNetSD_T2VBase.forward / _forward_single, unet/unet_t2v.py:210-348 (use_fps_condition
     False, y given).  The block structure is recovered from the state_dict keys."""
     b, c, f, h, w = x.shape
@@ -190,9 +206,11 @@ def unet_forward(sd, x, t, y, dim):
             x5 = temporal_transformer(sd, p, x5)
             return x5.permute(0, 2, 1, 3, 4).reshape(bf, cc, hh, ww)
         if kind == "down":
-            return F.conv2d(x, sd[p + ".op.weight"], sd[p + ".op.bias"], stride=2, padding=1)
+            return F.conv2d(x, sd[p + ".op.weight"], sd[p + ".op.bias"], stride=2, padding=down_padding)
         if kind == "up":
             x = F.interpolate(x, scale_factor=2, mode="nearest")
+            if up_crop:
+                x = x[..., up_crop:-up_crop, :]
             return F.conv2d(x, sd[p + ".conv.weight"], sd[p + ".conv.bias"], padding=1)
         raise KeyError(p)
 
@@ -217,7 +235,12 @@ def unet_forward(sd, x, t, y, dim):
     x = run_list("middle_block", x)
     i = 0
     while any(k.startswith(f"output_blocks.{i}.") for k in sd):
-        x = torch.cat([x, xs.pop()], dim=1)
+        skip = xs.pop()
+        if freeu is not None and i < len(freeu):        # unet_sr600.py:274-287
+            x = x.clone()
+            x[:, : x.shape[1] // 2] = x[:, : x.shape[1] // 2] * freeu[i][0]
+            skip = fourier_filter(skip, 1, freeu[i][1])
+        x = torch.cat([x, skip], dim=1)
         x = run_list(f"output_blocks.{i}", x)
         i += 1
     x = F.conv2d(F.silu(_gn(sd, "out.0", x, 1e-5)), sd["out.2.weight"], sd["out.2.bias"], padding=1)

@@ -142,3 +142,16 @@ def test_sampler_uses_batched_units_when_available(emu_backend):
     seq = lambda x, tt, **k: m(x, tt, **k)                 # plain callable -> two sequential calls
     b, _ = d.ddim_sample(g["x"], t, seq, kw, guide_scale=9.0, ddim_timesteps=50)
     assert rel_l2(a, b) < 1e-5
+
+
+# ---- UNetSD_SR600 (trunk variant) ----------------------------------------------------
+def test_sr600_oracle_and_host_logic_vs_reference_golden(emu_backend):
+    from vgen_amd.unet import UNetSD_SR600
+    g = gold("unet_sr600_tiny.pt")
+    sd = torch_ref.synth_state_dict(g["shapes"], seed=g["seed"])
+    assert rel_l2(torch_ref.unet_sr600_forward(sd, g["x"], g["t"], g["y"], g["cfg"]["dim"]), g["out"]) < 2e-5
+    m = UNetSD_SR600(**g["cfg"], compute_dtype="fp16").eval()
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v) for k, v in g["shapes"].items()}
+    m.load_state_dict(sd, strict=True)
+    out = m(g["x"], g["t"], g["y"], x_lr=None)
+    assert out.shape == g["out"].shape and rel_l2(out, g["out"]) < 3e-3

@@ -422,3 +422,94 @@ extern "C" int vgen_lincomb4(const float* a, const float* b, const float* c, con
                      cc, cd, out, n);
   return vgen_check_launch("lincomb4");
 }
+
+// ---------------------------------------------------------------------------------------------
+// UNetSD_SR600 skip filter + backbone boost (see include/vgen_hip.h)
+namespace {
+
+__global__ __launch_bounds__(256) void lowfreq_stats_kernel(const float* __restrict__ x, int H, int W, int C,
+                                                            float* __restrict__ st) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int64_t img = blockIdx.y;
+  if (c >= C) return;
+  const float th = 6.283185307179586f / (float)H, tw = 6.283185307179586f / (float)W;
+  float s[7] = {0, 0, 0, 0, 0, 0, 0};
+  const float* xi = x + img * H * W * C + c;
+  for (int h = 0; h < H; ++h) {
+    float sh, ch;
+    sincosf(th * h, &sh, &ch);
+    for (int w = 0; w < W; ++w) {
+      float sw, cw;
+      sincosf(tw * w, &sw, &cw);
+      const float v = xi[(int64_t)(h * W + w) * C];
+      s[0] += v;
+      s[1] += v * ch;
+      s[2] += v * sh;
+      s[3] += v * cw;
+      s[4] += v * sw;
+      s[5] += v * (ch * cw - sh * sw);   // cos(a + b)
+      s[6] += v * (sh * cw + ch * sw);   // sin(a + b)
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 7; ++k) st[(img * 7 + k) * C + c] = s[k];
+}
+
+__global__ __launch_bounds__(256) void lowfreq_apply_kernel(const float* __restrict__ x, int H, int W, int C,
+                                                            float gain, const float* __restrict__ st,
+                                                            float* __restrict__ y) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int64_t row = blockIdx.y;                 // img*H*W + h*W + w
+  if (c >= C) return;
+  const int hw = H * W;
+  const int64_t img = row / hw;
+  const int rem = (int)(row - img * hw);
+  const int h = rem / W, w = rem - h * W;
+  float sh, ch, sw, cw;
+  sincosf(6.283185307179586f / (float)H * h, &sh, &ch);
+  sincosf(6.283185307179586f / (float)W * w, &sw, &cw);
+  const float* s = st + img * 7 * C + c;
+  const float pr = s[0] + (s[C] * ch + s[2 * C] * sh) + (s[3 * C] * cw + s[4 * C] * sw) +
+                   (s[5 * C] * (ch * cw - sh * sw) + s[6 * C] * (sh * cw + ch * sw));
+  y[row * C + c] = x[row * C + c] + gain * pr;
+}
+
+__global__ __launch_bounds__(256) void scale_channels_kernel(float* __restrict__ x, int64_t M, int C, int c0,
+                                                             int c1, float sc) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int n = c1 - c0;
+  if (i >= M * n) return;
+  const int64_t m = i / n;
+  const int c = c0 + (int)(i - m * n);
+  x[m * C + c] *= sc;
+}
+
+}  // namespace
+
+extern "C" int vgen_lowfreq_filter(const float* x, int64_t nimg, int32_t H, int32_t W, int32_t C, float scale,
+                                   float* y, float* ws, size_t ws_bytes, void* stream) {
+  VGEN_REQUIRE(nimg > 0 && nimg <= 65535 && H > 0 && W > 0 && C > 0, "lowfreq_filter: sizes");
+  VGEN_REQUIRE((int64_t)nimg * H * W <= 65535, "lowfreq_filter: too many rows for one launch");
+  if (ws_bytes < (size_t)7 * nimg * C * sizeof(float)) {
+    vgen_set_error("lowfreq_filter: workspace too small");
+    return VGEN_E_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(lowfreq_stats_kernel, dim3((C + 255) / 256, (unsigned)nimg), dim3(256), 0, s, x, H, W, C, ws);
+  int rc = vgen_check_launch("lowfreq_stats");
+  if (rc) return rc;
+  const float gain = (scale - 1.0f) / (float)(H * W);
+  hipLaunchKernelGGL(lowfreq_apply_kernel, dim3((C + 255) / 256, (unsigned)(nimg * H * W)), dim3(256), 0, s, x, H,
+                     W, C, gain, ws, y);
+  return vgen_check_launch("lowfreq_apply");
+}
+
+extern "C" int vgen_scale_channels(float* x, int64_t M, int32_t C, int32_t c0, int32_t c1, float sc, void* stream) {
+  VGEN_REQUIRE(M >= 0 && C > 0 && c0 >= 0 && c1 <= C && c0 <= c1, "scale_channels: args");
+  const int64_t n = M * (c1 - c0);
+  if (n <= 0) return 0;
+  VGEN_REQUIRE((n + 255) / 256 < (1LL << 31), "scale_channels: too large");
+  hipLaunchKernelGGL(scale_channels_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     M, C, c0, c1, sc);
+  return vgen_check_launch("scale_channels");
+}

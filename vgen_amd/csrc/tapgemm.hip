@@ -178,7 +178,7 @@ __global__ __launch_bounds__(BM * 2) void tapgemm_kernel(const vgen_tapgemm_args
         d0 = tap / 3;
         d1 = tap - 3 * d0;
       }
-      const int Hv = p.Hi << p.ups, Wv = p.Wi << p.ups;
+      const int Hv = (p.Hi << p.ups) - 2 * p.crop_t, Wv = p.Wi << p.ups;
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
         int64_t row;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(BM * 2) void tapgemm_kernel(const vgen_tapgemm_args
           const int iy = rs[i].a + d0;
           const int ix = rs[i].b + d1;
           ok = (iy >= 0) & (iy < Hv) & (ix >= 0) & (ix < Wv);
-          row = (int64_t)rs[i].base + (int64_t)(iy >> p.ups) * p.Wi + (ix >> p.ups);
+          row = (int64_t)rs[i].base + (int64_t)((iy + p.crop_t) >> p.ups) * p.Wi + (ix >> p.ups);
         } else if (p.mode == VGEN_TAP_TEMPORAL3) {
           const int f2 = rs[i].a + tap - 1;
           ok = (f2 >= 0) & (f2 < p.F);
@@ -579,7 +579,8 @@ extern "C" int vgen_tapgemm(const vgen_tapgemm_args* args, void* stream) {
       break;
     case VGEN_TAP_CONV3X3:
       VGEN_REQUIRE(a.taps == 9 && a.Hi > 0 && a.Wi > 0 && a.Ho > 0 && a.Wo > 0 &&
-                       (a.stride == 1 || a.stride == 2) && (a.ups == 0 || a.ups == 1),
+                       (a.stride == 1 || a.stride == 2) && (a.ups == 0 || a.ups == 1) && a.crop_t >= 0 &&
+                       (a.crop_t == 0 || a.ups == 1),
                    "tapgemm: bad conv3x3 geometry");
       VGEN_REQUIRE(a.M % ((int64_t)a.Ho * a.Wo) == 0, "tapgemm: M not a multiple of Ho*Wo");
       VGEN_REQUIRE((a.M / ((int64_t)a.Ho * a.Wo)) * a.Hi * a.Wi < (1LL << 31),

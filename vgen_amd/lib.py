@@ -36,7 +36,7 @@ class TapGemmArgs(C.Structure):
         ("rows_per_rb", C.c_int64), ("residual", C.c_void_p), ("ldr", C.c_int64),
         ("out", C.c_void_p), ("ldo", C.c_int64), ("out_dtype", C.c_int32),
         ("epilogue", C.c_int32),
-        ("ws", C.c_void_p), ("ws_bytes", C.c_size_t),
+        ("ws", C.c_void_p), ("ws_bytes", C.c_size_t), ("crop_t", C.c_int32),
     ]
 
 
@@ -76,6 +76,8 @@ SYMBOLS = {
     "vgen_cfg_ddim_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _i64, _i64, _vp,
                                      _vp, _vp]),
     "vgen_gaussian_sample": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _f32, _vp, _vp]),
+    "vgen_lowfreq_filter": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
+    "vgen_scale_channels": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _f32, _vp]),
     "vgen_cfg_stats_ws_bytes": (_sz, [_i64]),
     "vgen_cfg_stats": (C.c_int, [_vp, _vp, _f32, _i32, _i64, _i64, _vp, _vp, _sz, _vp]),
     "vgen_gauss_x0": (C.c_int, [_vp, _vp, _vp, _f32, _vp, _i32, _i64, _i64, _vp, _vp, _vp]),

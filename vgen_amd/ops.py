@@ -40,6 +40,7 @@ class TapGemm:
     pad_t: int = 1
     pad_l: int = 1
     ups: int = 0
+    crop_t: int = 0
     F: int = 0
     S: int = 0
     A2: Optional[torch.Tensor] = None
@@ -159,7 +160,7 @@ class HipBackend:
         a.M, a.N, a.dtype = g.M, g.N, _ENUM[A.dtype]
         a.A, a.lda, a.C1, a.taps, a.mode = A.data_ptr(), A.stride(0), g.C1, g.taps, g.mode
         a.Hi, a.Wi, a.Ho, a.Wo = g.Hi, g.Wi, g.Ho, g.Wo
-        a.stride, a.pad_t, a.pad_l, a.ups = g.stride, g.pad_t, g.pad_l, g.ups
+        a.stride, a.pad_t, a.pad_l, a.ups, a.crop_t = g.stride, g.pad_t, g.pad_l, g.ups, g.crop_t
         a.F, a.S = g.F, g.S
         if g.A2 is not None:
             A2 = _mat(g.A2, "A2")
@@ -263,6 +264,22 @@ class HipBackend:
                                          _ptr(out), _ptr(x0), self._stream(xt))
         _lib.check(rc, "vgen_cfg_ddim_step")
         return out, x0
+
+    def lowfreq_filter(self, x, nimg, H, W, scale):
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[0] == nimg * H * W
+        C_ = x.shape[1]
+        y = torch.empty_like(x)
+        ws = torch.empty(7 * nimg * C_, dtype=torch.float32, device=x.device)
+        rc = self.lib.vgen_lowfreq_filter(_ptr(x), nimg, H, W, C_, float(scale), _ptr(y), _ptr(ws), ws.numel() * 4,
+                                          self._stream(x))
+        _lib.check(rc, "vgen_lowfreq_filter")
+        return y
+
+    def scale_channels(self, x, c0, c1, s):
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
+        rc = self.lib.vgen_scale_channels(_ptr(x), x.shape[0], x.shape[1], c0, c1, float(s), self._stream(x))
+        _lib.check(rc, "vgen_scale_channels")
+        return x
 
     def gauss_denoise(self, xt, y, u, guide, rescale, coef, pred_type, want_eps):
         """CFG (+guide_rescale) + x0 (+eps) of GaussianDiffusion.denoise; all fp32 contiguous."""

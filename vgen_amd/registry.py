@@ -97,9 +97,9 @@ DIFFUSION = Registry("DIFFUSION")
 def _native_classes():
     from .diffusion import DiffusionDDIM
     from .diffusion_gauss import DiffusionDDIMSR
-    from .unet import UNetSD_T2VBase
+    from .unet import UNetSD_SR600, UNetSD_T2VBase
     from .vae import AutoencoderKL
-    return {"MODEL": [UNetSD_T2VBase], "AUTO_ENCODER": [AutoencoderKL],
+    return {"MODEL": [UNetSD_T2VBase, UNetSD_SR600], "AUTO_ENCODER": [AutoencoderKL],
             "DIFFUSION": [DiffusionDDIM, DiffusionDDIMSR]}
 
 

@@ -126,16 +126,18 @@ class _TemporalTransformerP(nn.Module):
 
 
 class _DownP(nn.Module):
-    # reference: Downsample(use_conv=True, dims=2), util.py:929-953
+    # reference: Downsample(use_conv=True, dims=2), util.py:929-953 (padding=(2,1) in UNetSD_SR600)
     def __init__(self, c, padding=1):
         super().__init__()
+        self.pad = (padding, padding) if isinstance(padding, int) else tuple(padding)
         self.op = nn.Conv2d(c, c, 3, stride=2, padding=padding)
 
 
 class _UpP(nn.Module):
-    # reference: Upsample(use_conv=True), util.py:743-771
-    def __init__(self, c):
+    # reference: Upsample(use_conv=True), util.py:743-771; UpsampleSR600 (:774-804) crops one row top/bottom
+    def __init__(self, c, crop=0):
         super().__init__()
+        self.crop = crop
         self.conv = nn.Conv2d(c, c, 3, padding=1)
 
 
@@ -179,6 +181,10 @@ def _f32(t):
 
 # ------------------------------------------------------------------------------------------
 class UNetSD_T2VBase(nn.Module):
+    _down_padding = 1          # Downsample conv padding (SR600: (2, 1))
+    _up_crop = 0               # rows cropped after the nearest-2x upsample (SR600: 1)
+    _freeu = None              # SR600: ((backbone boost, skip low-frequency scale), ...) for decoder blocks 0, 1
+
     def __init__(self, config=None, in_dim=4, dim=512, y_dim=512, context_dim=512, hist_dim=156,
                  dim_condition=4, out_dim=6, num_tokens=4, dim_mult=[1, 2, 3, 4], num_heads=None,
                  head_dim=64, num_res_blocks=3, attn_scales=[1 / 2, 1 / 4, 1 / 8],
@@ -230,7 +236,7 @@ class UNetSD_T2VBase(nn.Module):
                 self.input_blocks.append(block)
                 shortcut_dims.append(cout)
                 if i != len(dim_mult) - 1 and j == num_res_blocks - 1:
-                    self.input_blocks.append(_DownP(cout))
+                    self.input_blocks.append(_DownP(cout, self._down_padding))
                     shortcut_dims.append(cout)
                     scale /= 2.0
         # middle (unet_t2v.py:150-172)
@@ -249,7 +255,7 @@ class UNetSD_T2VBase(nn.Module):
                     block.append(_TemporalTransformerP(cout, cout // head_dim))
                 cin = cout
                 if i != len(dim_mult) - 1 and j == num_res_blocks:
-                    block.append(_UpP(cout))
+                    block.append(_UpP(cout, self._up_crop))
                     scale *= 2.0
                 self.output_blocks.append(block)
         self.out = _seq(nn.GroupNorm(32, cout), None, nn.Conv2d(cout, self.out_dim, 3, padding=1))
@@ -390,12 +396,14 @@ class UNetSD_T2VBase(nn.Module):
         W, b = Wb if isinstance(Wb, tuple) else (Wb, None)
         return ops.backend().tapgemm(TapGemm(A=A, W=W, M=M, N=W.shape[0], C1=A.shape[1], bias=b, **kw))
 
-    def _conv3x3(self, A, Wb, nimg, Hi, Wi, C1, stride=1, ups=0, **kw):
+    def _conv3x3(self, A, Wb, nimg, Hi, Wi, C1, stride=1, ups=0, pad=(1, 1), crop=0, **kw):
         W, b = Wb
-        Ho = (Hi << ups) // stride if stride == 1 else ((Hi << ups) + 2 - 3) // 2 + 1
-        Wo = (Wi << ups) // stride if stride == 1 else ((Wi << ups) + 2 - 3) // 2 + 1
+        Hv, Wv = (Hi << ups) - 2 * crop, Wi << ups          # (virtual) conv input size
+        Ho = (Hv + 2 * pad[0] - 3) // stride + 1
+        Wo = (Wv + 2 * pad[1] - 3) // stride + 1
         g = TapGemm(A=A, W=W, M=nimg * Ho * Wo, N=W.shape[0], C1=C1, mode=L.TAP_CONV3X3, taps=9,
-                    Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo, stride=stride, pad_t=1, pad_l=1, ups=ups, bias=b, **kw)
+                    Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo, stride=stride, pad_t=pad[0], pad_l=pad[1], ups=ups,
+                    crop_t=crop, bias=b, **kw)
         return ops.backend().tapgemm(g), Ho, Wo
 
     def _resblock(self, rb: _ResBlockP, x1, x2, emb_all, B, F, H, W):
@@ -569,11 +577,11 @@ class UNetSD_T2VBase(nn.Module):
                 return self._temporal_tx(mod, h, B, F, H, W), H, W
             if isinstance(mod, _DownP):
                 a = be.act_cast(h, 0, dt)
-                o, Ho, Wo = self._conv3x3(a, P[mod._pname], B * F, H, W, h.shape[1], stride=2)
+                o, Ho, Wo = self._conv3x3(a, P[mod._pname], B * F, H, W, h.shape[1], stride=2, pad=mod.pad)
                 return o, Ho, Wo
             if isinstance(mod, _UpP):
                 a = be.act_cast(h, 0, dt)
-                o, Ho, Wo = self._conv3x3(a, P[mod._pname], B * F, H, W, h.shape[1], ups=1)
+                o, Ho, Wo = self._conv3x3(a, P[mod._pname], B * F, H, W, h.shape[1], ups=1, crop=mod.crop)
                 return o, Ho, Wo
             raise TypeError(type(mod))
 
@@ -587,9 +595,15 @@ class UNetSD_T2VBase(nn.Module):
             xs.append((h, H, W))
         for m in self.middle_block:
             h, H, W = run(m, h, None, H, W)
-        for blk in self.output_blocks:
+        for bnum, blk in enumerate(self.output_blocks):
             skip, Hs, Ws = xs.pop()
             assert (Hs, Ws) == (H, W)
+            if self._freeu is not None and bnum < len(self._freeu):
+                # UNetSD_SR600 (unet_sr600.py:274-287): boost the first half of the backbone channels and
+                # damp the skip's lowest spatial frequencies (Fourier_filter, threshold 1)
+                boost, lf = self._freeu[bnum]
+                h = be.scale_channels(h, 0, h.shape[1] // 2, boost)
+                skip = be.lowfreq_filter(skip, B * F, H, W, lf)
             x2 = skip
             for m in blk:
                 h, H, W = run(m, h, x2, H, W)
@@ -603,3 +617,31 @@ class UNetSD_T2VBase(nn.Module):
         be.pointwise_small(o, B * F, F, od, H, W, (sFHW * od, H * W * od, 1, W * od, od),
                            P["eye"], None, od, out, (od * sFHW, H * W, sFHW, W, 1))
         return out
+
+
+class UNetSD_SR600(UNetSD_T2VBase):
+    """MI355X-native drop-in for the reference's 600p super-resolution UNet (unet_sr600.py:52-389): the t2v
+    trunk with Downsample(padding=(2, 1)) (:151), UpsampleSR600's one-row crop (util.py:801) and the
+    FreeU-style backbone boost / skip low-frequency damping on the first two decoder blocks (:274-287).
+    Same parameter names as the reference class; `forward(x, t, y, x_lr=None, fps=None, ...)`."""
+    _down_padding = (2, 1)
+    _up_crop = 1
+    _freeu = ((1.1, 0.6), (1.2, 0.4))
+
+    def __init__(self, in_dim=7, dim=512, y_dim=512, context_dim=512, out_dim=6, dim_mult=[1, 2, 3, 4],
+                 num_heads=None, head_dim=64, num_res_blocks=3, attn_scales=[1 / 2, 1 / 4, 1 / 8],
+                 use_scale_shift_norm=True, dropout=0.1, temporal_attn_times=1, temporal_attention=True,
+                 use_checkpoint=False, use_image_dataset=False, use_sim_mask=False, inpainting=True,
+                 compute_dtype=None, **kwargs):
+        super().__init__(in_dim=in_dim, dim=dim, y_dim=y_dim, context_dim=context_dim, out_dim=out_dim,
+                         dim_mult=dim_mult, num_heads=num_heads, head_dim=head_dim,
+                         num_res_blocks=num_res_blocks, attn_scales=attn_scales, dropout=dropout,
+                         temporal_attn_times=temporal_attn_times, temporal_attention=temporal_attention,
+                         use_checkpoint=use_checkpoint, use_image_dataset=use_image_dataset,
+                         use_sim_mask=use_sim_mask, inpainting=inpainting, use_fps_condition=False,
+                         compute_dtype=compute_dtype)
+
+    @torch.no_grad()
+    def forward(self, x, t, y, x_lr=None, fps=None, video_mask=None, focus_present_mask=None,
+                prob_focus_present=0., mask_last_frame_num=0, **kwargs):
+        return super().forward(x, t, y=y)
