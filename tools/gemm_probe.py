@@ -25,6 +25,16 @@ def main():
               ("lin 57344x2560x320 geglu", dict(M=57344, N=2560, K=320, geglu=True)),
               ("lin 14336x5120x640 geglu", dict(M=14336, N=5120, K=640, geglu=True)),
               ("lin 3584x1280x1280 res", dict(M=3584, N=1280, K=1280, res=True)),
+              ("lin 14336x640x640 res", dict(M=14336, N=640, K=640, res=True)),
+              ("lin 57344x960x320 qkv", dict(M=57344, N=960, K=320)),
+              ("lin 57344x320x1280 ff2", dict(M=57344, N=320, K=1280, res=True)),
+              ("lin 3584x10240x1280 geglu", dict(M=3584, N=10240, K=1280, geglu=True)),
+              ("lin 3584x3840x1280 qkv", dict(M=3584, N=3840, K=1280)),
+              ("lin 3584x1280x5120 ff2", dict(M=3584, N=1280, K=5120, res=True)),
+              ("lin 896x1280x1280 res", dict(M=896, N=1280, K=1280, res=True)),
+              ("tconv 3584x1280x3840", dict(temporal=(2, 16, 112), C=1280)),
+              ("tconv 896x1280x3840", dict(temporal=(2, 16, 28), C=1280)),
+              ("conv 896x1280x(9*1280)", dict(conv=(32, 4, 7), C=1280, N=1280)),
               ("conv 57344x320x(9*320)", dict(conv=(32, 32, 56), C=320, N=320)),
               ("conv 14336x640x(9*640)", dict(conv=(32, 16, 28), C=640, N=640)),
               ("conv 3584x1280x(9*1280)", dict(conv=(32, 8, 14), C=1280, N=1280)),

@@ -38,15 +38,16 @@
 
 namespace {
 
-constexpr int BK = 64;          // K elements per tile (128 bytes per row)
-constexpr int ROW_BYTES = 128;  // BK * 2
-// Two block shapes (template parameters BM / WM / STAGES of the kernel):
-//   "big"   BM = 256, 4x2 waves (512 threads), 3-stage ring, one block per CU  — long-K GEMMs
-//   "small" BM = 128, 2x2 waves (256 threads), 2-stage ring, two blocks per CU — the two blocks are
-//           not barrier-coupled, so one block's MFMAs cover the other's fragment-read / epilogue
-//           bubbles, and 512 tile slots halve the tile-quantisation loss of short launches.
-constexpr int WN = 2;
-
+// Two block shapes of ONE kernel template (BM x BN tile, BK K-elements per stage, WM x WN waves):
+//   "pp"   256 x BN, BK = 64, 4x2 waves (512 threads), 3-stage ring, ONE block per CU, ping-pong wave
+//          groups (below) — the long-K shape: convs, big linears.
+//   "dual" 256 x BN, BK = 32, 2x2 waves (256 threads, wave tile 128 x BN/2), 3-stage ring of 24-26 KiB
+//          stages, TWO blocks per CU (<= 80 KiB LDS, <= 256 VGPRs each).  The two blocks are not
+//          barrier-coupled: one block's prologue (index math, first DMA latency), fragment reads and
+//          epilogue (GELU, residual traffic, stores) run under the other's MFMAs.  The short-K
+//          linears of the transformer blocks (5-20 K-steps per tile) spend 60-80 % of a "pp" tile in
+//          exactly those phases (ablation in profiles/).  The 128-row wave tile also reads 25 % fewer
+//          LDS bytes per MFMA than the 64 x 64 one.
 struct RowState {
   int base;  // LINEAR/TEMPORAL: source row m; CONV: img * Hi * Wi
   int a;     // CONV: iy0 ; TEMPORAL: frame index
@@ -70,19 +71,39 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <typename T, int BM, int BN, int STAGES>
-__global__ __launch_bounds__(BM * 2) void tapgemm_kernel(const vgen_tapgemm_args p, const int splitk,
-                                                         float* __restrict__ ws) {
-  constexpr int WM = BM / 64;                   // waves along M (wave tile is 64 rows)
-  constexpr int NT = WM * WN * 64;              // threads (= 2 * BM)
-  constexpr int RPP = NT / 8;                   // tile rows covered by one DMA pass of the block
-  constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile 64 x {64, 80, 32}
+// LDS rows are BK 16-bit elements = CPR 16-byte chunks.  The DMA destination is lane-linear, so the
+// bank swizzle is applied to the per-lane SOURCE chunk and again on the fragment reads.
+//   CPR = 8 (128-B rows): chunk ^ (row & 7)
+//   CPR = 4 ( 64-B rows): chunk ^ f[(row >> 2) & 3], f = {0, 3, 2, 1} — with ds_read_b128's 16-lane
+//           groups {0-3, 12-15, 20-27}, ... every group then covers all 64 banks exactly once.
+template <int CPR>
+__device__ __forceinline__ int swz_key(int row) {
+  if constexpr (CPR == 8) {
+    return row & 7;
+  } else {
+    const int q = (row >> 2) & 3;
+    return (4 - q) & 3;
+  }
+}
+
+template <typename T, int BM, int BN, int BK, int WM, int WN, int STAGES, bool PP>
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_kernel(
+    const vgen_tapgemm_args p, const int splitk, float* __restrict__ ws) {
+  static_assert(!PP || (WM * WN == 8 && STAGES == 3), "ping-pong needs 8 waves and a 3-stage ring");
+  constexpr int NT = WM * WN * 64;              // threads
+  constexpr int ROW_BYTES = BK * 2;             // bytes per LDS tile row
+  constexpr int CPR = ROW_BYTES / 16;           // 16-byte chunks per row
+  constexpr int RPI = 64 / CPR;                 // tile rows written by one DMA wave-instruction (1 KiB)
+  constexpr int RPP = NT / CPR;                 // tile rows covered by one DMA pass of the block
+  constexpr int KS = BK / 32;                   // MFMA k-steps per K-tile
+  constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
   constexpr int MF = WTM / 16, NF = WTN / 16;   // fragments per wave
   constexpr int RA = BM / RPP;                  // A DMA passes per tile (4)
   constexpr int RBF = BN / RPP;                 // full W passes
-  constexpr int RBT = BN % RPP;                 // tail rows of W: only waves with wave*8 < RBT issue
+  constexpr int RBT = BN % RPP;                 // tail rows of W: only waves with wave*RPI < RBT issue
   constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
   constexpr int LPT = RA + RBF;                 // DMA instructions per wave per tile (+1 with tail)
+  static_assert(BM % RPP == 0 && RBT % RPI == 0, "tile rows must split into whole DMA instructions");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -93,7 +114,7 @@ __global__ __launch_bounds__(BM * 2) void tapgemm_kernel(const vgen_tapgemm_args
   const int wn = wave % WN;
   const int lr = lane & 15;  // row within a 16-row fragment
   const int lq = lane >> 4;  // 16-lane group: k-chunk (operands) / 4-row group (C/D)
-  const bool w_tail = RBT > 0 && wave * 8 < RBT;
+  const bool w_tail = RBT > 0 && wave * RPI < RBT;
 
   // ---- XCD-aware tile renumbering (bijective for any grid size) ----------------------------
   const int tiles_n = (p.N + BN - 1) / BN;
@@ -111,9 +132,9 @@ __global__ __launch_bounds__(BM * 2) void tapgemm_kernel(const vgen_tapgemm_args
   const uint16_t* __restrict__ W = (const uint16_t*)p.W;
   const int64_t ldw = p.ldw ? p.ldw : (int64_t)p.taps * p.C1 + p.C2;
 
-  // ---- per-thread DMA assignment: LDS chunk position ld_c of tile rows ld_r + 64*i -----------
-  const int ld_c = tid & 7;
-  const int ld_r = tid >> 3;
+  // ---- per-thread DMA assignment: LDS chunk position ld_c of tile rows ld_r + RPP*i -----------
+  const int ld_c = tid % CPR;
+  const int ld_r = tid / CPR;
 
   RowState rs[RA];
   unsigned mvalid = 0;
@@ -155,7 +176,7 @@ __global__ __launch_bounds__(BM * 2) void tapgemm_kernel(const vgen_tapgemm_args
 
   // ---- incremental per-lane DMA source pointers ---------------------------------------------
   // pc[j] = source of piece j for the NEXT K-tile to issue; consecutive K-tiles inside one tap /
-  // K segment just advance by 128 bytes (0 for rows that read the zero line), so the steady-state
+  // K segment just advance by ROW_BYTES (0 for rows that read the zero line), so the steady-state
   // cost is one 64-bit add per piece; the row gather is recomputed only when the tap changes.
   // (v3a recomputed rows, bounds and 64-bit products every K-tile: ~700 ALU instructions per wave
   // per K-tile against 32 MFMAs — the loop was issue-bound, not memory- or MFMA-bound.)
@@ -163,12 +184,12 @@ __global__ __launch_bounds__(BM * 2) void tapgemm_kernel(const vgen_tapgemm_args
   const char* pc[NP];
   int inc[NP];
   const char* const zline = (const char*)&g_zero16;
-  const int src_cb = (ld_c ^ (ld_r & 7)) * 16;   // byte offset of this lane's source chunk
-  const int wave_row0 = wave * 8;                // first tile row written by this wave's DMA (+64*i)
+  const int src_cb = (ld_c ^ swz_key<CPR>(ld_r)) * 16;   // byte offset of this lane's source chunk
+  const int wave_row0 = wave * RPI;              // first tile row written by this wave's DMA (+RPP*i)
   int kt_next = kt_begin;                        // K-tile the pointers currently describe
   int left;                                      // K-tiles until the A pointers must be regathered
 
-  auto gather_a = [&](int kt) {                  // (re)compute pc[0..RA) for K-tile kt
+  auto gather_a = [&](int kt) __attribute__((always_inline)) {   // (re)compute pc[0..RA) for K-tile kt
     if (kt < T1) {
       const int tap = kt / cpt1;
       const int cch = kt - tap * cpt1;
@@ -218,7 +239,7 @@ __global__ __launch_bounds__(BM * 2) void tapgemm_kernel(const vgen_tapgemm_args
     pc[RA + i] = ok ? (const char*)(W + (int64_t)n * ldw + (int64_t)kt_begin * BK) + src_cb : zline;
     inc[RA + i] = ok ? ROW_BYTES : 0;
   }
-  auto advance = [&]() {                         // pointers -> next K-tile
+  auto advance = [&]() __attribute__((always_inline)) {   // pointers -> next K-tile
     ++kt_next;
     if (--left == 0) {
       if (kt_next < KT) gather_a(kt_next);
@@ -230,11 +251,11 @@ __global__ __launch_bounds__(BM * 2) void tapgemm_kernel(const vgen_tapgemm_args
     for (int i = RA; i < NP; ++i) pc[i] += inc[i];
   };
   // LDS destination (wave-uniform) of piece j in `stage`
-  auto piece_dst = [&](int stage, int j) -> unsigned char* {
+  auto piece_dst = [&](int stage, int j) __attribute__((always_inline)) -> unsigned char* {
     unsigned char* const base = smem + stage * STAGE_BYTES + wave_row0 * ROW_BYTES;
     return j < RA ? base + j * RPP * ROW_BYTES : base + (BM + (j - RA) * RPP) * ROW_BYTES;
   };
-  auto load_tile = [&](int stage) {   // prologue: issue all pieces of the next K-tile back to back
+  auto load_tile = [&](int stage) __attribute__((always_inline)) {   // all pieces of the next K-tile back to back
 #pragma unroll
     for (int j = 0; j < LPT; ++j) glds16(pc[j], piece_dst(stage, j));
     if (RBT > 0 && w_tail) glds16(pc[NP - 1], piece_dst(stage, NP - 1));
@@ -247,74 +268,165 @@ __global__ __launch_bounds__(BM * 2) void tapgemm_kernel(const vgen_tapgemm_args
 #pragma unroll
     for (int mi = 0; mi < MF; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // fragment read offsets: row (frag*16 + lr), chunk (ks*4 + lq) ^ (lr & 7)
+  // fragment read offsets: row (frag*16 + lr), chunk (ks*4 + lq) ^ key(lr)
   const int rd_row = lr * ROW_BYTES;
-  const int sw = lr & 7;
+  const int sw = swz_key<CPR>(lr);
 
-  // Multiply one staged K-tile and, interleaved with the MFMAs, issue the DMA pieces of the tile
-  // two steps ahead.  An LDS-DMA instruction occupies the CU's single texture-address path for
-  // ~16-25 cycles (1 KiB at <= 64 B/clk) and stalls the issuing wave ~100 cycles; issued in one
-  // burst by all 8 waves right after the barrier (v3a) the DMA phase and the MFMA phase simply
-  // added up (ablation: 142 us compute-only + 116 us DMA-only - 41 us fixed = 207 us measured at
-  // 4096^3).  Spread one piece per MFMA group, the partner wave on the SIMD keeps the matrix pipe
-  // busy while this wave waits on the address path.
-  auto compute = [&](int stage, auto prefetch_tag, int stage_pf) {
-    constexpr bool prefetch = decltype(prefetch_tag)::value;   // compile-time: branch-free K-step body
-    const unsigned char* a = smem + stage * STAGE_BYTES + wm * WTM * ROW_BYTES + rd_row;
+  // A fragments are read in MH passes of MFH row fragments (the 128-row wave tile of the dual shape
+  // would otherwise hold 32 + 16 operand registers on top of 128 accumulators and spill)
+  constexpr int MH = MF > 4 ? MF / 4 : 1;
+  constexpr int MFH = MF / MH;
+  u32x4 wf[KS][NF], xf[KS][MFH];
+  auto read_w = [&](int stage) __attribute__((always_inline)) {
     const unsigned char* b = smem + stage * STAGE_BYTES + BM * ROW_BYTES + wn * WTN * ROW_BYTES + rd_row;
-    u32x4 wf[2][NF], xf[2][MF];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       const int co = ((ks * 4 + lq) ^ sw) << 4;
 #pragma unroll
       for (int ni = 0; ni < NF; ++ni) wf[ks][ni] = *(const u32x4*)(b + ni * 16 * ROW_BYTES + co);
-#pragma unroll
-      for (int mi = 0; mi < MF; ++mi) xf[ks][mi] = *(const u32x4*)(a + mi * 16 * ROW_BYTES + co);
     }
-    constexpr int NMF = 2 * NF * MF;                 // MFMAs per K-tile per wave
+  };
+  auto read_x = [&](int stage, int mh) __attribute__((always_inline)) {
+    const unsigned char* a = smem + stage * STAGE_BYTES + (wm * WTM + mh * MFH * 16) * ROW_BYTES + rd_row;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int co = ((ks * 4 + lq) ^ sw) << 4;
+#pragma unroll
+      for (int mi = 0; mi < MFH; ++mi) xf[ks][mi] = *(const u32x4*)(a + mi * 16 * ROW_BYTES + co);
+    }
+  };
+
+  // Lock-step K-step (dual shape): multiply one staged K-tile and, interleaved with the MFMAs, issue
+  // the DMA pieces of the tile two steps ahead.  An LDS-DMA instruction occupies the CU's single
+  // texture-address path for ~16-25 cycles (1 KiB at <= 64 B/clk) and stalls the issuing wave ~100
+  // cycles; issued in one burst right after the barrier (v3a) the DMA phase and the MFMA phase
+  // simply added up.  Spread one piece per MFMA group, the other waves on the SIMD keep the matrix
+  // pipe busy while this wave waits on the address path.
+  auto compute = [&](int stage, auto prefetch_tag, int stage_pf) __attribute__((always_inline)) {
+    constexpr bool prefetch = decltype(prefetch_tag)::value;   // compile-time: branch-free K-step body
+    constexpr int NMF = KS * NF * MF;                // MFMAs per K-tile per wave
+    constexpr int NMH = NMF / MH;
     constexpr int GRP = NMF / NP;                    // MFMAs between two DMA pieces (>= NP slots)
     static_assert(GRP >= 1 && (NMF + GRP - 1) / GRP >= NP, "not enough MFMA groups for the DMA pieces");
+    read_w(stage);
     int piece = 0;
 #pragma unroll
-    for (int i = 0; i < NMF; ++i) {
-      const int ks = i / (NF * MF), r = i % (NF * MF), ni = r / MF, mi = r % MF;
-      if (i % GRP == 0) {
-        if (prefetch) {
-          if (piece < LPT) glds16(pc[piece], piece_dst(stage_pf, piece));
-          else if (RBT > 0 && piece == NP - 1 && w_tail) glds16(pc[NP - 1], piece_dst(stage_pf, NP - 1));
+    for (int mh = 0; mh < MH; ++mh) {
+      read_x(stage, mh);
+#pragma unroll
+      for (int j = 0; j < NMH; ++j) {
+        const int i = mh * NMH + j;
+        const int ks = j / (NF * MFH), r = j % (NF * MFH), ni = r / MFH, mi = r % MFH;
+        if (i % GRP == 0) {
+          if (prefetch) {
+            if (piece < LPT) glds16(pc[piece], piece_dst(stage_pf, piece));
+            else if (RBT > 0 && piece == NP - 1 && w_tail) glds16(pc[NP - 1], piece_dst(stage_pf, NP - 1));
+          }
+          ++piece;
+          __builtin_amdgcn_sched_barrier(0);
         }
-        ++piece;
-        __builtin_amdgcn_sched_barrier(0);
+        acc[ni][mh * MFH + mi] = T::mfma32(wf[ks][ni], xf[ks][mi], acc[ni][mh * MFH + mi]);
       }
-      acc[ni][mi] = T::mfma32(wf[ks][ni], xf[ks][mi], acc[ni][mi]);
+      if (MH > 1) __builtin_amdgcn_sched_barrier(0);   // the next pass reuses xf: keep its reads below
     }
     if (prefetch) advance();
   };
 
-  // ---- main loop: STAGES-deep DMA ring, one barrier per K-tile, counted vmcnt ------------------
-  // Iteration `it`: wait until tile `it` has landed (with 3 stages the DMA of tile it+1 may stay in
-  // flight), barrier (publishes tile `it` of every wave AND proves every wave finished reading the
-  // stage that the next DMA overwrites, last read in iteration it-1), issue tile it+STAGES-1
-  // interleaved with the MFMAs of tile it.
+  // ---- ping-pong schedule (PP) -----------------------------------------------------------------
+  // Waves w and w+4 share a SIMD.  With one barrier per K-tile both sit in the same phase: they read
+  // fragments together (matrix pipe idle), then fight for the pipe together — SQ counters of the
+  // lock-step 8-wave loop: 38 % of wave cycles parked at s_waitcnt/s_barrier, MFMA pipe 48 % busy.
+  // Here every K-tile is split into an R phase (16 fragment ds_reads + the 6 DMA pieces of tile t+2
+  // + the counted vmcnt for tile t+1) and an M phase (32 back-to-back MFMAs out of registers), each
+  // closed by a barrier, and waves 4-7 run ONE PHASE BEHIND waves 0-3 (one extra barrier up front,
+  // one at the end for the leaders): on every SIMD one wave multiplies while its partner reads.
+  //   hazards: DMA(t+2) overwrites the stage of tile t-1, last read in R(t-1) of both groups, i.e.
+  //   before the barrier that precedes the earlier group's R(t);  tile t+1 is complete once every
+  //   wave passed the vmcnt at the end of its R(t), which for both groups is before any R(t+1).
+  auto read_phase = [&](int stage, auto prefetch_tag, int stage_pf) __attribute__((always_inline)) {
+    constexpr bool prefetch = decltype(prefetch_tag)::value;
+    static_assert(!PP || MH == 1, "ping-pong keeps a whole K-tile of fragments in registers");
+    read_w(stage);
+    read_x(stage, 0);
+    if (prefetch) {
+#pragma unroll
+      for (int j = 0; j < LPT; ++j) glds16(pc[j], piece_dst(stage_pf, j));
+      if (RBT > 0 && w_tail) glds16(pc[NP - 1], piece_dst(stage_pf, NP - 1));
+      advance();
+    }
+  };
+  auto mfma_phase = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int ni = 0; ni < NF; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MF; ++mi) acc[ni][mi] = T::mfma32(wf[ks][ni], xf[ks][mi], acc[ni][mi]);
+  };
+
+  // ---- main loop: STAGES-deep DMA ring, counted vmcnt -------------------------------------------
+  // Two sequential loops — `nk - AHEAD` K-steps that also issue the DMA of tile it+AHEAD, then the
+  // last AHEAD steps without — rather than one loop with an if/else around two bodies: the diamond
+  // made hipcc give every accumulator a second register for the join (2 x 128 on the dual shape =
+  // spills to scratch inside the K loop).
   constexpr int AHEAD = STAGES - 1;
   for (int i = 0; i < AHEAD; ++i)
     if (nk > i) load_tile(i);
   int st_c = 0, st_l = AHEAD;   // stage to compute / stage to load into
-  for (int it = 0; it < nk; ++it) {
-    if (STAGES == 3 && it + 1 < nk) {
-      if (w_tail) wait_vmcnt<LPT + 1>();
-      else wait_vmcnt<LPT>();
-    } else {
-      wait_vmcnt<0>();
-    }
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    // two straight-line bodies (with / without prefetch) instead of a per-piece branch: hipcc can
-    // then count lgkmcnt for the fragment reads instead of draining all 16 before the first MFMA
-    if (it + AHEAD < nk) compute(st_c, std::true_type{}, st_l);
-    else compute(st_c, std::false_type{}, st_l);
+  const int nk_main = nk > AHEAD ? nk - AHEAD : 0;
+  auto rotate = [&]() __attribute__((always_inline)) {
     st_c = st_c == STAGES - 1 ? 0 : st_c + 1;
     st_l = st_l == STAGES - 1 ? 0 : st_l + 1;
+  };
+  auto wait_next = [&]() __attribute__((always_inline)) {   // all but the newest tile's pieces have landed
+    if (w_tail) wait_vmcnt<LPT + 1>();
+    else wait_vmcnt<LPT>();
+  };
+  if constexpr (PP) {
+    const bool follower = wave >= 4;
+    if (nk > 1) wait_next();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();                       // tile 0 published
+    if (follower) __builtin_amdgcn_s_barrier();         // run one phase behind
+    asm volatile("" ::: "memory");
+    auto pp_step = [&](auto prefetch_tag, bool more) __attribute__((always_inline)) {
+      read_phase(st_c, prefetch_tag, st_l);
+      // tile it+1 (issued one iteration ago) must have landed before the NEXT read phase of anyone
+      if (more) wait_next();
+      else wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_phase();
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      rotate();
+    };
+    for (int it = 0; it < nk_main; ++it) pp_step(std::true_type{}, true);
+    for (int it = nk_main; it < nk; ++it) pp_step(std::false_type{}, false);
+    if (!follower) __builtin_amdgcn_s_barrier();
+  } else {
+    // Iteration `it`: wait until tile `it` has landed (the DMA of tile it+1 may stay in flight),
+    // barrier (publishes tile `it` of every wave AND proves every wave finished reading the stage
+    // that the next DMA overwrites, last read in iteration it-1), issue tile it+AHEAD interleaved
+    // with the MFMAs of tile it.
+    for (int it = 0; it < nk_main; ++it) {
+      if (STAGES == 3) wait_next();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      compute(st_c, std::true_type{}, st_l);
+      rotate();
+    }
+    for (int it = nk_main; it < nk; ++it) {
+      if (STAGES == 3 && it + 1 < nk) wait_next();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      compute(st_c, std::false_type{}, st_l);
+      rotate();
+    }
   }
 
   if (splitk > 1) {   // raw fp32 partial tile -> workspace [split][M][N]; epilogue in the reducer
@@ -352,6 +464,9 @@ __global__ __launch_bounds__(BM * 2) void tapgemm_kernel(const vgen_tapgemm_args
   }
 #pragma unroll
   for (int mi = 0; mi < MF; ++mi) {
+    // keep the residual / row-bias loads of one row fragment from being hoisted above the stores of
+    // the previous one: with 8 row fragments the hoisted loads alone would need > 100 VGPRs
+    __builtin_amdgcn_sched_barrier(0);
     const int64_t m = m0 + wm * WTM + mi * 16 + lr;
     if (m >= p.M) continue;
     const float* rbp = p.rowbias ? p.rowbias + (m / p.rows_per_rb) * p.rowbias_ld : nullptr;
@@ -438,19 +553,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vgen_tapgemm_a
 }
 
 // ---- launch planning ---------------------------------------------------------------------------
-// One block per CU and 256-row tiles make tile-count quantisation expensive (280 tiles = 2 rounds
-// at 55 % fill), so the column tile BN and the split-K factor are chosen together from a small
-// cost model (microseconds; constants fitted to profiles/r01_v3_tapgemm_shapes.json):
-//   cost = rounds(tiles * s) * (ceil(KT / s) * t_ktile(BN) + t_tile) + [s > 1] * reduce(s)
-// relative K-step time and per-tile fixed cost of the small (128-row, 2 blocks / CU) shape
-constexpr double kSmallRel = 1.6;
-constexpr double kSmallFixed = 6.0;
+// 256-row tiles make tile-count quantisation expensive (280 tiles on 256 CUs = 2 rounds at 55 %
+// fill), so the block shape, the column tile BN and the split-K factor are chosen together from a
+// small cost model (microseconds; constants fitted to profiles/r01_*_tapgemm_shapes.json):
+//   cost = rounds(tiles * s / slots) * (ceil(KT / s) * t_ktile + t_tile) + [s > 1] * reduce(s)
+// with KT in 64-element K-steps, slots = 256 ("pp", one block per CU) or 512 ("dual").
+enum Shape { SHAPE_PP = 0, SHAPE_DUAL = 1, SHAPE_PP128 = 2 };
 
 struct Plan {
-  int bm;
+  int shape;
   int bn;
   int splitk;
 };
+
+int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
 
 Plan make_plan(const vgen_tapgemm_args& a) {
   const bool geglu = a.epilogue == VGEN_EPI_GEGLU;
@@ -463,27 +582,44 @@ Plan make_plan(const vgen_tapgemm_args& a) {
   if (a.N % 128 == 0) cands[nc++] = 128;
   if (a.N % 160 == 0 && !geglu) cands[nc++] = 160;
   if (nc == 0) cands[nc++] = 64;
-  static const int force_bm = getenv("VGEN_TAPGEMM_FORCE_BM") ? atoi(getenv("VGEN_TAPGEMM_FORCE_BM")) : 0;
+  // tuning switches (not part of the ABI): VGEN_TAPGEMM_SHAPE = 0 (pp) / 1 (dual) / 2 (pp128) forces a shape
+  static const int force_shape = env_int("VGEN_TAPGEMM_SHAPE", -1);
   const int smax = vec ? (KT / 4 < 32 ? KT / 4 : 32) : 1;
-  Plan best{256, cands[0], 1};
+  // HBM time of the epilogue traffic (output + fp32 residual), not hidden behind MFMAs when every CU
+  // runs one block in the same phase ("pp"); about half hidden with two independent blocks per CU
+  const double epi_us = (double)a.M * n_out * ((a.out_dtype == VGEN_F32 ? 4 : 2) + (a.residual ? 4 : 0)) / 4.5e6;
+  Plan best{SHAPE_PP, cands[0], 1};
   double best_cost = 1e30;
-  for (int bm = 256; bm >= 128; bm -= 128) {
-    if (force_bm && bm != force_bm) continue;
+  for (int shape = SHAPE_PP; shape <= SHAPE_PP128; ++shape) {
+    if (force_shape >= 0 && shape != force_shape) continue;
+    const int bm = shape == SHAPE_PP128 ? 128 : 256;
     const int64_t tiles_m = (a.M + bm - 1) / bm;
-    const int slots = bm == 256 ? 256 : 512;          // co-resident blocks on the chip
     for (int c = 0; c < nc; ++c) {
       const int bn = cands[c];
-      // time of one K-step of one block (us); a small block shares its CU with a second one
-      const double t_ktile = (bn == 160 ? 1.45 : (bn == 128 ? 1.2 : 0.75)) * (bm == 256 ? 1.0 : kSmallRel);
-      const double t_tile = bm == 256 ? 6.0 : kSmallFixed;
+      const int bi = bn == 128 ? 0 : (bn == 160 ? 1 : 2);
+      // us per 64-element K-step of one block: pp alone on its CU; dual alone / sharing the CU
+      static const double t_pp[3] = {0.85, 1.15, 0.60};
+      static const double t_d1[3] = {1.10, 1.30, 0.75};
+      static const double t_d2[3] = {2.20, 2.50, 1.40};
+      static const double t_p128[3] = {0.62, 0.80, 0.45};
       const int64_t tiles = tiles_m * ((a.N + bn - 1) / bn);
       for (int s = 1; s <= (smax < 1 ? 1 : smax); ++s) {
-        const int64_t rounds = (tiles * s + slots - 1) / slots;
-        double cost = (double)rounds * (((KT + s - 1) / s) * t_ktile + t_tile);
+        const int64_t blocks = tiles * s;
+        const int kts = (KT + s - 1) / s;
+        double cost;
+        if (shape == SHAPE_PP) {
+          cost = (double)((blocks + 255) / 256) * (kts * t_pp[bi] + 8.0) + epi_us;
+        } else if (shape == SHAPE_PP128) {
+          cost = (double)((blocks + 255) / 256) * (kts * t_p128[bi] + 6.0) + epi_us;
+        } else if (blocks <= 256) {
+          cost = kts * t_d1[bi] + 10.0 + epi_us;
+        } else {
+          cost = (double)((blocks + 511) / 512) * (kts * t_d2[bi] + 9.0) + 0.5 * epi_us + 1.0;
+        }
         if (s > 1) cost += 5.0 + (double)(s + 1) * a.M * a.N * 4.0 / 3.0e6;   // partials at ~3 TB/s
         if (cost < best_cost - 1e-9) {
           best_cost = cost;
-          best = Plan{bm, bn, s};
+          best = Plan{shape, bn, s};
         }
       }
     }
@@ -491,12 +627,12 @@ Plan make_plan(const vgen_tapgemm_args& a) {
   return best;
 }
 
-template <typename T, int BM, int BN, int STAGES>
+template <typename T, int BM, int BN, int BK, int WM, int WN, int STAGES, bool PP>
 int launch(const vgen_tapgemm_args& a, int splitk, hipStream_t stream) {
-  constexpr size_t lds = (size_t)STAGES * (BM + BN) * ROW_BYTES;
+  constexpr size_t lds = (size_t)STAGES * (BM + BN) * BK * 2;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)tapgemm_kernel<T, BM, BN, STAGES>,
+    hipError_t e = hipFuncSetAttribute((const void*)tapgemm_kernel<T, BM, BN, BK, WM, WN, STAGES, PP>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       vgen_set_error("tapgemm: hipFuncSetAttribute(%zu B LDS) failed: %s", lds,
@@ -515,8 +651,8 @@ int launch(const vgen_tapgemm_args& a, int splitk, hipStream_t stream) {
   }
   if (splitk > 1 && (a.ws == nullptr || a.ws_bytes < (size_t)splitk * a.M * a.N * sizeof(float)))
     splitk = 1;   // caller did not provide the workspace: still correct, just fewer blocks
-  hipLaunchKernelGGL((tapgemm_kernel<T, BM, BN, STAGES>), dim3((unsigned)grid, (unsigned)splitk),
-                     dim3(BM * 2), lds, stream, a, splitk, (float*)a.ws);
+  hipLaunchKernelGGL((tapgemm_kernel<T, BM, BN, BK, WM, WN, STAGES, PP>), dim3((unsigned)grid, (unsigned)splitk),
+                     dim3(WM * WN * 64), lds, stream, a, splitk, (float*)a.ws);
   int rc = vgen_check_launch("tapgemm");
   if (rc || splitk == 1) return rc;
   const int n_out = a.epilogue == VGEN_EPI_GEGLU ? a.N / 2 : a.N;
@@ -529,17 +665,24 @@ int launch(const vgen_tapgemm_args& a, int splitk, hipStream_t stream) {
 template <typename T>
 int dispatch(const vgen_tapgemm_args& a, hipStream_t s) {
   const Plan pl = make_plan(a);
-  if (pl.bm == 256) {
+  if (pl.shape == SHAPE_PP) {
     switch (pl.bn) {
-      case 128: return launch<T, 256, 128, 3>(a, pl.splitk, s);
-      case 160: return launch<T, 256, 160, 3>(a, pl.splitk, s);
-      default: return launch<T, 256, 64, 3>(a, pl.splitk, s);
+      case 128: return launch<T, 256, 128, 64, 4, 2, 3, true>(a, pl.splitk, s);
+      case 160: return launch<T, 256, 160, 64, 4, 2, 3, true>(a, pl.splitk, s);
+      default: return launch<T, 256, 64, 64, 4, 2, 3, true>(a, pl.splitk, s);
+    }
+  }
+  if (pl.shape == SHAPE_PP128) {
+    switch (pl.bn) {
+      case 128: return launch<T, 128, 128, 64, 4, 2, 3, true>(a, pl.splitk, s);
+      case 160: return launch<T, 128, 160, 64, 4, 2, 3, true>(a, pl.splitk, s);
+      default: return launch<T, 128, 64, 64, 4, 2, 3, true>(a, pl.splitk, s);
     }
   }
   switch (pl.bn) {
-    case 128: return launch<T, 128, 128, 2>(a, pl.splitk, s);
-    case 160: return launch<T, 128, 160, 2>(a, pl.splitk, s);
-    default: return launch<T, 128, 64, 2>(a, pl.splitk, s);
+    case 128: return launch<T, 256, 128, 32, 2, 2, 3, false>(a, pl.splitk, s);
+    case 160: return launch<T, 256, 160, 32, 2, 2, 3, false>(a, pl.splitk, s);
+    default: return launch<T, 256, 64, 32, 2, 2, 3, false>(a, pl.splitk, s);
   }
 }
 
