@@ -251,6 +251,10 @@ GN_CASES = [  # nb, S, C1, C2, silu, raw
     (16, 128, 320, 0, True, False), (2, 96, 1280, 640, True, True), (1, 256, 64, 0, False, False),
     (3, 50, 128, 0, True, False), (1, 37, 2560, 0, True, False), (2, 1792, 320, 0, True, False),
     (2, 33, 640, 320, True, True),
+    # group slice > 64 KiB: the three-launch streaming path (smaller slices take the single-launch kernel)
+    (2, 1792, 1280, 0, True, False), (3, 1001, 640, 640, True, True), (2, 12000, 320, 0, True, False),
+    # single-launch kernel: slice just under the LDS bound, two-source rows, odd row counts
+    (5, 409, 1280, 0, True, False), (3, 271, 640, 1280, False, True),
 ]
 LN_CASES = [(100, 320), (7, 1280), (300, 64), (5, 512), (1, 2048)]
 

@@ -13,7 +13,7 @@ def timeit(fn, n=20):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-for nb, S, C in [(2, 28672, 320), (32, 1792, 320), (2, 7168, 640), (2, 1792, 1280), (2, 448, 1280), (32, 28, 1280)]:
+for nb, S, C in [(2, 28672, 320), (32, 1792, 320), (2, 7168, 640), (2, 1792, 1280), (2, 448, 1280), (32, 28, 1280), (32, 448, 640), (32, 112, 1280), (32, 112, 2560), (32, 28, 2560)]:
     x = torch.randn(nb * S, C, device=dev); g = torch.ones(C, device=dev); b = torch.zeros(C, device=dev)
     us = timeit(lambda: be.groupnorm(x, None, nb, S, 32, 1e-5, g, b, True, False, dt))
     print(f"gn nb={nb} S={S} C={C}: {us:.1f} us  {nb*S*C*10/us/1e3:.0f} GB/s")

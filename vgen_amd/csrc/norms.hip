@@ -12,6 +12,7 @@
 // The reduction order is fixed (no atomics) so results are run-to-run deterministic.
 // The input row is the virtual concat [x1 | x2] (decoder skip connections).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -217,6 +218,92 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(
   }
 }
 
+// ---- single-launch GroupNorm for small tensors ------------------------------------------------
+// The three-launch pipeline above costs ~18-28 us on the 4x7 / 8x14 levels of the UNet no matter how
+// small the tensor is (three dependent launches, each with its own ramp and tail).  When one
+// (batch, group) slice fits 96 KiB of LDS, one block per slice does everything: load once into LDS
+// while summing, centred variance from LDS, then normalise + affine + SiLU + 16-bit store (12 us).
+// Larger slices stay on the streaming pipeline: a single block per slice is latency-bound (one CU
+// pulls ~20 GB/s with 16 KiB in flight; measured 51 us vs 26 us on [2 x 1792 x 1280]).
+// Fixed reduction order: wave butterflies, then the wave partials in index order.
+constexpr int GNF_THREADS = 512;
+constexpr int GNF_LDS_FLOATS = 24576;   // 96 KiB of the CU's 160 KiB
+
+__device__ __forceinline__ float gnf_block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();                       // red[] may still be read from the previous reduction
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < GNF_THREADS / 64; ++i) t += red[i];
+  return t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(
+    const float* __restrict__ x1, int C1, const float* __restrict__ x2, int C2, int64_t S, int groups,
+    float eps, const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
+    uint16_t* __restrict__ y, uint16_t* __restrict__ raw) {
+  extern __shared__ __attribute__((aligned(16))) float gnf_stage[];
+  __shared__ float red[GNF_THREADS / 64];
+  const int C = C1 + C2;
+  const int cpg = C / groups;
+  const int I = cpg >> 1;                       // float2 items per row of this group
+  const int rpi = GNF_THREADS / I;              // rows per block iteration
+  const int tid = threadIdx.x;
+  const int r0 = tid / I;
+  const int i = tid - r0 * I;
+  const bool active = r0 < rpi;
+  const int c = blockIdx.x * cpg + 2 * i;       // this thread's channel pair
+  const int64_t row0 = (int64_t)blockIdx.y * S;
+  const bool from1 = c < C1;
+  const float* src = from1 ? x1 + row0 * C1 + c : x2 + row0 * C2 + (c - C1);
+  const int64_t lds = from1 ? C1 : C2;
+  const int nit = active ? (int)((S - r0 + rpi - 1) / rpi) : 0;
+  f32x2* const st = (f32x2*)gnf_stage + r0 * I + i;   // this thread's column of the staged slice
+  const int sstep = rpi * I;
+
+  float a = 0.f;
+  {
+    const float* p = src + (int64_t)r0 * lds;
+    const int64_t step = (int64_t)rpi * lds;
+#pragma unroll 8
+    for (int k = 0; k < nit; ++k) {
+      const f32x2 v = *(const f32x2*)(p + k * step);
+      st[k * sstep] = v;
+      a += v.x + v.y;
+    }
+  }
+  const float n = (float)S * (float)cpg;
+  const float mean = gnf_block_sum(a, red) / n;
+  float q = 0.f;
+  for (int k = 0; k < nit; ++k) {
+    const f32x2 v = st[k * sstep];
+    const float d0 = v.x - mean, d1 = v.y - mean;
+    q += d0 * d0 + d1 * d1;
+  }
+  const float rstd = 1.0f / sqrtf(gnf_block_sum(q, red) / n + eps);
+  if (!active) return;
+  const float sc0 = gamma[c] * rstd, sc1 = gamma[c + 1] * rstd;
+  const float sh0 = beta[c] - mean * sc0, sh1 = beta[c + 1] - mean * sc1;
+  uint16_t* yo = y + (row0 + r0) * C + c;
+  uint16_t* ro = raw ? raw + (row0 + r0) * C + c : nullptr;
+  const int64_t ostep = (int64_t)rpi * C;
+#pragma unroll 4
+  for (int k = 0; k < nit; ++k) {
+    const f32x2 v = st[k * sstep];
+    float o0 = v.x * sc0 + sh0, o1 = v.y * sc1 + sh1;
+    if (silu) {
+      o0 = silu_f(o0);
+      o1 = silu_f(o1);
+    }
+    *(uint32_t*)(yo + k * ostep) = T::pack2(o0, o1);
+    if (ro) *(uint32_t*)(ro + k * ostep) = T::pack2(v.x, v.y);
+  }
+}
+
 int gn_nsplit(int64_t nb, int64_t S, int C) {
   // ~16 K elements (64 KiB of fp32) per block, but at least ~1024 blocks overall when the tensor
   // allows it (>= 2 rows per block): the 4x7 / 8x14 levels are latency-bound, not bandwidth-bound.
@@ -333,6 +420,40 @@ extern "C" int vgen_groupnorm(const float* x1, int32_t C1, const float* x2, int3
     vgen_set_error("groupnorm: workspace %zu < %zu", ws_bytes, vgen_groupnorm_ws_bytes(nb, S));
     return VGEN_E_WORKSPACE;
   }
+  hipStream_t s = (hipStream_t)stream;
+  {
+    // tuning switch (not part of the ABI): VGEN_GN_FUSED_MAX_MB (0 keeps everything on the streaming
+    // pipeline).  A slice row is only cpg * 4 bytes: at C = 320 (40 B) every 128-byte line is fetched by
+    // 3-4 blocks and big tensors lose (76 vs 53 us on [32 x 1792 x 320]); from 80-byte rows on the
+    // single launch wins as long as the slice fits the LDS (24 vs 40 us on [32 x 448 x 640]).
+    static const int env_max = getenv("VGEN_GN_FUSED_MAX_MB") ? atoi(getenv("VGEN_GN_FUSED_MAX_MB")) : -1;
+    const int64_t fused_max = (int64_t)(env_max >= 0 ? env_max : (C / groups >= 16 ? 96 : 24)) << 20;
+    const int cpg = C / groups;
+    if (nb * S * C * 4 <= fused_max && cpg % 2 == 0 && C1 % 2 == 0 && cpg / 2 <= GNF_THREADS && S * cpg <= GNF_LDS_FLOATS) {
+      const size_t lds = (size_t)S * cpg * sizeof(float);
+      static bool attr_done = false;
+      if (!attr_done) {
+        hipError_t e1 = hipFuncSetAttribute((const void*)gn_fused_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            GNF_LDS_FLOATS * 4);
+        hipError_t e2 = hipFuncSetAttribute((const void*)gn_fused_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            GNF_LDS_FLOATS * 4);
+        if (e1 != hipSuccess || e2 != hipSuccess) {
+          vgen_set_error("groupnorm: hipFuncSetAttribute(LDS) failed");
+          return VGEN_E_BADARG;
+        }
+        attr_done = true;
+      }
+      dim3 fgrid((unsigned)groups, (unsigned)nb);
+      if (dtype == VGEN_BF16) {
+        hipLaunchKernelGGL(gn_fused_kernel<BF16>, fgrid, dim3(GNF_THREADS), lds, s, x1, C1, x2, C2, S, groups, eps,
+                           gamma, beta, silu, (uint16_t*)y, (uint16_t*)raw);
+      } else {
+        hipLaunchKernelGGL(gn_fused_kernel<F16>, fgrid, dim3(GNF_THREADS), lds, s, x1, C1, x2, C2, S, groups, eps,
+                           gamma, beta, silu, (uint16_t*)y, (uint16_t*)raw);
+      }
+      return vgen_check_launch("gn_fused");
+    }
+  }
   // rpb * C must fit the LDS staging of gn_stats (3072 floats per plane)
   const int nslots = C / 4;
   const int rpb = nslots <= GN_THREADS ? GN_THREADS / nslots : 1;
@@ -340,7 +461,6 @@ extern "C" int vgen_groupnorm(const float* x1, int32_t C1, const float* x2, int3
   const int ns = gn_nsplit(nb, S, C);
   float* part = ws;
   float* stat = ws + nb * ns * GN_G * 3;
-  hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)ns, (unsigned)nb);
   hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_THREADS), 0, s, x1, C1, x2, C2, S, groups, ns,
                      part);
