@@ -256,7 +256,7 @@ GN_CASES = [  # nb, S, C1, C2, silu, raw
     # single-launch kernel: slice just under the LDS bound, two-source rows, odd row counts
     (5, 409, 1280, 0, True, False), (3, 271, 640, 1280, False, True),
 ]
-LN_CASES = [(100, 320), (7, 1280), (300, 64), (5, 512), (1, 2048)]
+LN_CASES = [(100, 320), (7, 1280), (300, 64), (5, 512), (1, 2048), (40003, 320), (9001, 640), (3, 1024), (700, 1280), (50, 192)]
 
 
 def tapgemm_cases(dt):
