@@ -68,6 +68,19 @@ int vgen_groupnorm(const float* x1, int32_t C1, const float* x2, int32_t C2,
                    void* y, void* raw, int32_t dtype,
                    float* ws, size_t ws_bytes, void* stream);
 
+/* Same operator when the producer of x1 / x2 already left per-column statistics behind
+ * (vgen_tapgemm_args.colstats): the statistics pass over the fp32 input — 40 % of the streaming
+ * GroupNorm's HBM traffic — is replaced by a reduction of the column partials.
+ *   cs1 : [nb*S / 64][2][C1] fp32 — for every 64-row slab of x1: plane 0 = column sums, plane 1 =
+ *         column sums of squares (exactly what vgen_tapgemm writes); cs2 likewise for x2 (C2 > 0).
+ * Requires S % 64 == 0 (slabs must not straddle two normalisation batches). */
+int vgen_groupnorm_cs(const float* x1, int32_t C1, const float* cs1,
+                      const float* x2, int32_t C2, const float* cs2,
+                      int64_t nb, int64_t S, int32_t groups, float eps,
+                      const float* gamma, const float* beta, int32_t silu,
+                      void* y, void* raw, int32_t dtype,
+                      float* ws, size_t ws_bytes, void* stream);
+
 /* LayerNorm over the last dim, fp32 in -> 16-bit out (eps 1e-5 in the reference).
  * Replaces nn.LayerNorm norm1/2/3 of BasicTransformerBlock (util.py:692-694,700-704).
  * x [M, d] fp32 (row stride d), d % 4 == 0, d <= 2048. */
@@ -146,6 +159,11 @@ typedef struct vgen_tapgemm_args {
   size_t ws_bytes;
   int32_t crop_t;  /* CONV3X3 with ups: rows cropped from the top AND bottom of the upsampled image
                       before the conv (UpsampleSR600: x[..., 1:-1, :], util.py:801) */
+  float* colstats; /* optional [ceil(M/64)][2][N] fp32: per 64-row slab of the FINAL fp32 output, plane 0
+                      = column sums, plane 1 = column sums of squares (rows >= M excluded).  Lets the
+                      GroupNorm that consumes `out` (util.py:846,870,1663-1681) skip its statistics pass
+                      (vgen_groupnorm_cs).  Needs out_dtype = F32, no GEGLU, N % 4 == 0, ldo/ldr/
+                      rowbias_ld % 4 == 0; the launch is then never split along K. */
 } vgen_tapgemm_args;
 
 /* Launches whose tile count cannot fill the 256 CUs (small M: the 4x7 / 8x14 UNet levels) are

@@ -26,12 +26,26 @@ class EmuBackend:
 
     # -- norms ---------------------------------------------------------------------------------
     def groupnorm(self, x1, x2, nb, S, groups, eps, gamma, beta, silu, want_raw, dt):
+        from vgen_amd.ops import CS_ROWS, colstats_of
         x = x1 if x2 is None else torch.cat([x1, x2], 1)
         C = x.shape[1]
         assert C % 4 == 0 and C % groups == 0 and x1.shape[1] % 4 == 0
         v = x.view(nb, S, groups, C // groups).float()
-        mean = v.mean(dim=(1, 3), keepdim=True)
-        var = v.var(dim=(1, 3), unbiased=False, keepdim=True)
+        cs1 = colstats_of(x1, nb * S)
+        cs2 = colstats_of(x2, nb * S) if x2 is not None else None
+        if S % CS_ROWS == 0 and cs1 is not None and (x2 is None or cs2 is not None):
+            # vgen_groupnorm_cs: statistics come from the producers' column partials, not from x — a stale
+            # or mis-plumbed partial shows up as a parity failure of the host-logic tests
+            cs = cs1 if cs2 is None else torch.cat([cs1, cs2], 2)
+            t = cs.double().view(nb, S // CS_ROWS, 2, groups, C // groups).sum(dim=(1, 4))   # [nb, 2, groups]
+            n = S * (C // groups)
+            mean64 = t[:, 0] / n
+            var64 = (t[:, 1] / n - mean64 * mean64).clamp_min(0)
+            mean = mean64.float().view(nb, 1, groups, 1)
+            var = var64.float().view(nb, 1, groups, 1)
+        else:
+            mean = v.mean(dim=(1, 3), keepdim=True)
+            var = v.var(dim=(1, 3), unbiased=False, keepdim=True)
         y = ((v - mean) / torch.sqrt(var + eps)).view(nb * S, C) * gamma + beta
         if silu:
             y = y * torch.sigmoid(y)
@@ -105,6 +119,13 @@ class EmuBackend:
             out = torch.empty((g.M, n_out), dtype=g.out_dtype)
         assert out.dtype == g.out_dtype and out.dtype in (torch.float32, dt)
         out[:, :n_out] = acc.to(g.out_dtype)
+        if g.colstats:
+            assert g.out_dtype == torch.float32 and g.epilogue == L.EPI_NONE and g.N % 4 == 0
+            ns = (g.M + 63) // 64
+            pad = torch.zeros((ns * 64, g.N), dtype=torch.float32)
+            pad[: g.M] = acc
+            pv = pad.view(ns, 64, g.N)
+            out.vgen_cs = torch.stack([pv.sum(1), (pv * pv).sum(1)], 1).contiguous()
         return out
 
     # -- attention -------------------------------------------------------------------------------
@@ -193,7 +214,9 @@ class EmuBackend:
         return (v + (scale - 1.0) / (H * W) * acc).float().view(nimg * H * W, C)
 
     def scale_channels(self, x, c0, c1, s):
+        from vgen_amd.ops import drop_colstats
         x[:, c0:c1] *= s
+        drop_colstats(x)
         return x
 
     def gauss_denoise(self, xt, y, u, guide, rescale, coef, pred_type, want_eps):

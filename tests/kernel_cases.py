@@ -65,6 +65,32 @@ def case_groupnorm(be, dev, dt, nb, S, C1, C2, silu, raw, eps=1e-5, seed=0):
     return res
 
 
+def case_groupnorm_cs(be, dev, dt, nb, S, C1, C2, silu, seed=0):
+    """GroupNorm fed by producer column statistics (vgen_groupnorm_cs): x1 / x2 are tap-GEMM outputs."""
+    assert S % 64 == 0
+    g1 = make_tapgemm(dt, nb * S, C1, 64, residual=True, colstats=True, seed=seed)
+    g2 = make_tapgemm(dt, nb * S, C2, 128, colstats=True, seed=seed + 1) if C2 else None
+    gen = _g(seed + 2)
+    C = C1 + C2
+    gamma = 1 + 0.2 * torch.randn(C, generator=gen)
+    beta = 0.3 * torch.randn(C, generator=gen)
+    x1r = EMU.tapgemm(g1)
+    x2r = EMU.tapgemm(g2) if g2 else None
+    y_ref, _ = EMU.groupnorm(x1r, x2r, nb, S, 32, 1e-5, gamma, beta, silu, False, dt)
+    x1 = be.tapgemm(_clone_spec(g1, dev))
+    x2 = be.tapgemm(_clone_spec(g2, dev)) if g2 else None
+    assert getattr(x1, "vgen_cs", None) is not None
+    y, _ = be.groupnorm(x1, x2, nb, S, 32, 1e-5, gamma.to(dev), beta.to(dev), silu, False, dt)
+    # and the statistics path must agree with the plain path on the same device tensors
+    x1p = x1.clone()
+    x2p = x2.clone() if x2 is not None else None
+    y_plain, _ = be.groupnorm(x1p, x2p, nb, S, 32, 1e-5, gamma.to(dev), beta.to(dev), silu, False, dt)
+    return {"y": stats(y, y_ref), "y_vs_plain": stats(y, y_plain)}
+
+
+GN_CS_CASES = [(2, 12032, 320, 0, True), (3, 1792, 640, 640, True), (2, 448, 1280, 0, False), (4, 4096, 256, 128, True)]
+
+
 def case_layernorm(be, dev, dt, M, d, seed=0):
     g = _g(seed)
     x = torch.randn(M, d, generator=g) * 2 + 0.5
@@ -109,6 +135,8 @@ def case_tapgemm(be, dev, spec, want_map=False):
     ref = EMU.tapgemm(spec)
     out = be.tapgemm(_clone_spec(spec, dev))
     res = {"out": stats(out, ref)}
+    if spec.colstats:
+        res["colstats"] = stats(out.vgen_cs, ref.vgen_cs)
     if want_map:
         d = (out.float().cpu() - ref.float()).abs()
         M, N = d.shape
@@ -291,6 +319,13 @@ def tapgemm_cases(dt):
     c["lin_splitk_out16"] = make_tapgemm(dt, 300, 256, 2048, out_dtype=dt)
     c["temporal_splitk"] = make_tapgemm(dt, 2 * 4 * 28, 640, 640, mode=L.TAP_TEMPORAL3, F=4, S=28, residual=True)
     c["temporal"] = make_tapgemm(dt, 2 * 5 * 24, 64, 64, mode=L.TAP_TEMPORAL3, F=5, S=24, residual=True)
+    # column statistics for the consuming GroupNorm: ragged M (last slab partial), every shape family
+    c["cs_lin_1000x320"] = make_tapgemm(dt, 1000, 320, 320, residual=True, colstats=True)
+    c["cs_conv_rowbias"] = make_tapgemm(dt, 6 * 24 * 20, 128, 64, mode=L.TAP_CONV3X3, nimg=6, Hi=24, Wi=20, Ho=24, Wo=20,
+                                        rowbias=3 * 24 * 20, colstats=True)
+    c["cs_temporal_K2"] = make_tapgemm(dt, 2 * 8 * 96, 640, 640, mode=L.TAP_TEMPORAL3, F=8, S=96, residual=True,
+                                       colstats=True)
+    c["cs_lin_wide_dual"] = make_tapgemm(dt, 9000, 1280, 128, colstats=True)
     c["temporal_b128"] = make_tapgemm(dt, 1 * 16 * 28, 128, 128, mode=L.TAP_TEMPORAL3, F=16, S=28)
     return c
 

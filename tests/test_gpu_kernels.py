@@ -24,6 +24,12 @@ def test_groupnorm(hip_backend, dtname, case):
 
 
 @pytest.mark.parametrize("dtname", ["bf16", "fp16"])
+@pytest.mark.parametrize("case", kc.GN_CS_CASES, ids=lambda c: "nb%d_S%d_C%d+%d" % c[:4])
+def test_groupnorm_from_colstats(hip_backend, dtname, case):
+    _check(kc.case_groupnorm_cs(hip_backend, DEV, kc.DTS[dtname], *case), dtname)
+
+
+@pytest.mark.parametrize("dtname", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", kc.LN_CASES, ids=lambda c: "M%d_d%d" % c)
 def test_layernorm(hip_backend, dtname, case):
     _check(kc.case_layernorm(hip_backend, DEV, kc.DTS[dtname], *case), dtname)
@@ -37,7 +43,10 @@ _TG = sorted(kc.tapgemm_cases(torch.bfloat16))
 def test_tapgemm(hip_backend, dtname, name):
     spec = kc.tapgemm_cases(kc.DTS[dtname])[name]
     res = kc.case_tapgemm(hip_backend, DEV, spec)
+    cs = res.pop("colstats", None)
     _check(res, dtname, out_is_16=spec.out_dtype != torch.float32)
+    if cs is not None:
+        assert cs["finite"] and cs["rel_l2"] <= 2e-5, cs
 
 
 _AT = sorted(kc.attn_cases(torch.bfloat16))

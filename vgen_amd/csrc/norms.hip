@@ -164,6 +164,95 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
   }
 }
 
+// finalize from column partials (vgen_groupnorm_cs): one 256-thread block per (batch, group); items
+// are (64-row slab, channel) pairs of the group, each (n = 64, mean, M2) from its (sum, sumsq).
+// Threads fold items tid, tid + 256, ... (4 loads in flight), waves fold by butterfly, the 4 wave
+// results are merged in index order.  (First version: one wave, one dependent load pair per step —
+// 70 serial L2 round trips per launch, as slow as the statistics pass it replaced.)
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb_, float mb, float m2b) {
+  const float nt = n + nb_;
+  if (nt > 0.f) {
+    const float d = mb - mean;
+    const float w = nb_ / nt;
+    m2 = m2 + m2b + d * d * (n * w);
+    mean = mean + d * w;
+  }
+  n = nt;
+}
+
+__global__ __launch_bounds__(256) void gn_finalize_cs_kernel(const float* __restrict__ cs1, int C1,
+                                                             const float* __restrict__ cs2, int C2,
+                                                             int64_t S, int groups, float eps,
+                                                             float* __restrict__ stat) {
+  __shared__ float red[4][3];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int grp = blockIdx.x;
+  const int64_t nb = blockIdx.y;
+  const int cpg = (C1 + C2) / groups;
+  const int slabs = (int)(S / 64);
+  const int items = slabs * cpg;
+  const int64_t srow0 = nb * slabs;
+  float n = 0.f, mean = 0.f, m2 = 0.f;
+  auto fetch = [&](int it, float& sm, float& sq) __attribute__((always_inline)) {
+    const int sl = it / cpg;
+    const int c = grp * cpg + (it - sl * cpg);
+    const int64_t srow = srow0 + sl;
+    if (c < C1) {
+      sm = cs1[(srow * 2) * C1 + c];
+      sq = cs1[(srow * 2 + 1) * C1 + c];
+    } else {
+      sm = cs2[(srow * 2) * C2 + (c - C1)];
+      sq = cs2[(srow * 2 + 1) * C2 + (c - C1)];
+    }
+  };
+  int it = tid;
+  for (; it + 3 * 256 < items; it += 4 * 256) {
+    float sm[4], sq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) fetch(it + u * 256, sm[u], sq[u]);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float mb = sm[u] * (1.0f / 64.f);
+      chan_merge(n, mean, m2, 64.f, mb, fmaxf(sq[u] - sm[u] * mb, 0.f));
+    }
+  }
+  for (; it < items; it += 256) {
+    float sm, sq;
+    fetch(it, sm, sq);
+    const float mb = sm * (1.0f / 64.f);
+    chan_merge(n, mean, m2, 64.f, mb, fmaxf(sq - sm * mb, 0.f));
+  }
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float n2 = __shfl_xor(n, o, 64), mean2 = __shfl_xor(mean, o, 64),
+                m22 = __shfl_xor(m2, o, 64);
+    // symmetric form: both partners compute bit-identical results
+    const float nt = n + n2;
+    if (nt > 0.f) {
+      const float lo_n = (lane & o) ? n2 : n, hi_n = (lane & o) ? n : n2;
+      const float lo_m = (lane & o) ? mean2 : mean, hi_m = (lane & o) ? mean : mean2;
+      const float d = hi_m - lo_m;
+      const float wgt = hi_n / nt;
+      m2 = m2 + m22 + d * d * (lo_n * wgt);
+      mean = lo_m + d * wgt;
+    }
+    n = nt;
+  }
+  if (lane == 0) {
+    red[w][0] = n;
+    red[w][1] = mean;
+    red[w][2] = m2;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float N = red[0][0], M = red[0][1], Q = red[0][2];
+    for (int k = 1; k < 4; ++k) chan_merge(N, M, Q, red[k][0], red[k][1], red[k][2]);
+    const float var = N > 0.f ? Q / N : 0.f;
+    stat[(nb * groups + grp) * 2 + 0] = M;
+    stat[(nb * groups + grp) * 2 + 1] = 1.0f / sqrtf(var + eps);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(
     const float* __restrict__ x1, int C1, const float* __restrict__ x2, int C2, int64_t S,
@@ -477,11 +566,11 @@ extern "C" size_t vgen_groupnorm_ws_bytes(int64_t nb, int64_t S) {
   return (size_t)(nb * ns * GN_G * 3 + nb * GN_G * 2) * sizeof(float);
 }
 
-extern "C" int vgen_groupnorm(const float* x1, int32_t C1, const float* x2, int32_t C2,
-                              int64_t nb, int64_t S, int32_t groups, float eps,
-                              const float* gamma, const float* beta, int32_t silu, void* y,
-                              void* raw, int32_t dtype, float* ws, size_t ws_bytes,
-                              void* stream) {
+static int groupnorm_impl(const float* x1, int32_t C1, const float* cs1, const float* x2, int32_t C2,
+                          const float* cs2, int64_t nb, int64_t S, int32_t groups, float eps,
+                          const float* gamma, const float* beta, int32_t silu, void* y,
+                          void* raw, int32_t dtype, float* ws, size_t ws_bytes,
+                          void* stream) {
   const int C = C1 + C2;
   VGEN_REQUIRE(dtype == VGEN_BF16 || dtype == VGEN_F16, "groupnorm: dtype");
   VGEN_REQUIRE(groups > 0 && groups <= GN_G && C % groups == 0, "groupnorm: C=%d groups=%d", C,
@@ -540,14 +629,22 @@ extern "C" int vgen_groupnorm(const float* x1, int32_t C1, const float* x2, int3
   float* part = ws;
   float* stat = ws + nb * ns * GN_G * 3;
   dim3 grid((unsigned)ns, (unsigned)nb);
-  hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_THREADS), 0, s, x1, C1, x2, C2, S, groups, ns,
-                     part);
-  int rc = vgen_check_launch("gn_stats");
-  if (rc) return rc;
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)groups, (unsigned)nb), dim3(64), 0, s, part,
-                     groups, ns, eps, stat);
-  rc = vgen_check_launch("gn_finalize");
-  if (rc) return rc;
+  int rc;
+  if (cs1 != nullptr) {
+    hipLaunchKernelGGL(gn_finalize_cs_kernel, dim3((unsigned)groups, (unsigned)nb), dim3(256), 0, s, cs1, C1,
+                       cs2, C2, S, groups, eps, stat);
+    rc = vgen_check_launch("gn_finalize_cs");
+    if (rc) return rc;
+  } else {
+    hipLaunchKernelGGL(gn_stats_kernel, grid, dim3(GN_THREADS), 0, s, x1, C1, x2, C2, S, groups, ns,
+                       part);
+    rc = vgen_check_launch("gn_stats");
+    if (rc) return rc;
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)groups, (unsigned)nb), dim3(64), 0, s, part,
+                       groups, ns, eps, stat);
+    rc = vgen_check_launch("gn_finalize");
+    if (rc) return rc;
+  }
   if (dtype == VGEN_BF16) {
     hipLaunchKernelGGL(gn_apply_kernel<BF16>, grid, dim3(GN_THREADS), 0, s, x1, C1, x2, C2, S,
                        groups, ns, stat, gamma, beta, silu, (uint16_t*)y, (uint16_t*)raw);
@@ -556,6 +653,26 @@ extern "C" int vgen_groupnorm(const float* x1, int32_t C1, const float* x2, int3
                        groups, ns, stat, gamma, beta, silu, (uint16_t*)y, (uint16_t*)raw);
   }
   return vgen_check_launch("gn_apply");
+}
+
+extern "C" int vgen_groupnorm(const float* x1, int32_t C1, const float* x2, int32_t C2,
+                              int64_t nb, int64_t S, int32_t groups, float eps,
+                              const float* gamma, const float* beta, int32_t silu, void* y,
+                              void* raw, int32_t dtype, float* ws, size_t ws_bytes,
+                              void* stream) {
+  return groupnorm_impl(x1, C1, nullptr, x2, C2, nullptr, nb, S, groups, eps, gamma, beta, silu, y, raw,
+                        dtype, ws, ws_bytes, stream);
+}
+
+extern "C" int vgen_groupnorm_cs(const float* x1, int32_t C1, const float* cs1, const float* x2,
+                                 int32_t C2, const float* cs2, int64_t nb, int64_t S, int32_t groups,
+                                 float eps, const float* gamma, const float* beta, int32_t silu,
+                                 void* y, void* raw, int32_t dtype, float* ws, size_t ws_bytes,
+                                 void* stream) {
+  VGEN_REQUIRE(cs1 != nullptr && (C2 == 0 || cs2 != nullptr), "groupnorm_cs: missing column statistics");
+  VGEN_REQUIRE(S % 64 == 0, "groupnorm_cs: S=%lld must be a multiple of the 64-row slab", (long long)S);
+  return groupnorm_impl(x1, C1, cs1, x2, C2, cs2, nb, S, groups, eps, gamma, beta, silu, y, raw, dtype,
+                        ws, ws_bytes, stream);
 }
 
 extern "C" int vgen_layernorm(const float* x, int64_t M, int32_t d, float eps, const float* gamma,

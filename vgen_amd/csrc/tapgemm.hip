@@ -462,12 +462,57 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
       bv[ni] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   }
+  // column statistics of the final fp32 values per 64-row slab (vgen_tapgemm_args.colstats): the wave
+  // tile is 64 ("pp") or 128 ("dual") rows = 1 or 2 whole slabs, so no cross-wave step is needed.
+  // Each lane keeps partials over the 4 row fragments of a slab; the 16 lanes that hold different rows
+  // of the same 4 columns are then folded through the (now idle) stage LDS: [result][16 lanes] floats
+  // per wave, every lane sums one result row in a fixed order and stores it — 8 ds_write_b32 per
+  // fragment and 4 ds_read_b128 per result instead of a 4-step butterfly over 8 x NF registers
+  // (the ds_bpermute butterfly cost as much as the statistics pass it replaces).
+  const bool do_cs = p.colstats != nullptr && vec && !geglu;
+  f32x4 cs_s[NF], cs_q[NF];
+#pragma unroll
+  for (int ni = 0; ni < NF; ++ni) cs_s[ni] = cs_q[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (do_cs) __syncthreads();   // every wave is done reading the operand stages
+  auto flush_cs = [&](int slab) __attribute__((always_inline)) {
+    constexpr int NC = NF * 16;                                        // columns of this wave
+    constexpr int NRES = 2 * NC;                                       // sums | sums of squares
+    float* const cb = (float*)smem + wave * (NRES * 16);
+    const int64_t srow = (m0 + wm * WTM) / 64 + slab;                  // global slab index
+    const bool slab_live = srow * 64 < p.M;
+#pragma unroll
+    for (int ni = 0; ni < NF; ++ni) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int cw = ni * 16 + lq * 4 + r;
+        cb[cw * 16 + lr] = cs_s[ni][r];
+        cb[(NC + cw) * 16 + lr] = cs_q[ni][r];
+      }
+      cs_s[ni] = cs_q[ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // LDS operations of one wave execute in order: the reads below see the writes above
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int res = lane; res < NRES; res += 64) {
+      const f32x4* q = (const f32x4*)(cb + res * 16);
+      const f32x4 a = q[0], b = q[1], c = q[2], d = q[3];
+      const float t = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) +
+                      (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
+      const int plane = res >= NC ? 1 : 0;
+      const int n = n0 + wn * WTN + (res - plane * NC);
+      if (slab_live && n < p.N) p.colstats[(srow * 2 + plane) * (int64_t)p.N + n] = t;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads done before the next slab overwrites cb
+  };
 #pragma unroll
   for (int mi = 0; mi < MF; ++mi) {
     // keep the residual / row-bias loads of one row fragment from being hoisted above the stores of
     // the previous one: with 8 row fragments the hoisted loads alone would need > 100 VGPRs
     __builtin_amdgcn_sched_barrier(0);
     const int64_t m = m0 + wm * WTM + mi * 16 + lr;
+    if constexpr (MF % 4 == 0) {
+      if (do_cs && mi % 4 == 0 && mi > 0) flush_cs(mi / 4 - 1);
+    }
     if (m >= p.M) continue;
     const float* rbp = p.rowbias ? p.rowbias + (m / p.rows_per_rb) * p.rowbias_ld : nullptr;
     if (!geglu) {
@@ -480,6 +525,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
           v += bv[ni];
           if (rbp) v += *(const f32x4*)(rbp + n);
           if (p.residual) v += *(const f32x4*)(p.residual + m * p.ldr + n);
+          if (do_cs) {
+            cs_s[ni] += v;
+            cs_q[ni] += v * v;
+          }
           if (p.out_dtype == VGEN_F32) {
             *(f32x4*)(of + m * p.ldo + n) = v;
           } else {
@@ -516,6 +565,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
         }
       }
     }
+  }
+  if constexpr (MF % 4 == 0) {
+    if (do_cs) flush_cs(MF / 4 - 1);
   }
 }
 
@@ -584,14 +636,15 @@ Plan make_plan(const vgen_tapgemm_args& a) {
   if (nc == 0) cands[nc++] = 64;
   // tuning switches (not part of the ABI): VGEN_TAPGEMM_SHAPE = 0 (pp) / 1 (dual) / 2 (pp128) forces a shape
   static const int force_shape = env_int("VGEN_TAPGEMM_SHAPE", -1);
-  const int smax = vec ? (KT / 4 < 32 ? KT / 4 : 32) : 1;
+  const int smax = (vec && a.colstats == nullptr) ? (KT / 4 < 32 ? KT / 4 : 32) : 1;
   // HBM time of the epilogue traffic (output + fp32 residual), not hidden behind MFMAs when every CU
   // runs one block in the same phase ("pp"); about half hidden with two independent blocks per CU
   const double epi_us = (double)a.M * n_out * ((a.out_dtype == VGEN_F32 ? 4 : 2) + (a.residual ? 4 : 0)) / 4.5e6;
   Plan best{SHAPE_PP, cands[0], 1};
   double best_cost = 1e30;
   for (int shape = SHAPE_PP; shape <= SHAPE_PP128; ++shape) {
-    if (force_shape >= 0 && shape != force_shape) continue;
+    if (force_shape >= 0 && shape != force_shape && !(a.colstats && force_shape == SHAPE_PP128)) continue;
+    if (a.colstats && shape == SHAPE_PP128) continue;   // 32-row wave tiles: a slab would span two waves
     const int bm = shape == SHAPE_PP128 ? 128 : 256;
     const int64_t tiles_m = (a.M + bm - 1) / bm;
     for (int c = 0; c < nc; ++c) {
@@ -744,6 +797,12 @@ extern "C" int vgen_tapgemm(const vgen_tapgemm_args* args, void* stream) {
                  "tapgemm: GEGLU needs N %% 64 == 0, no rowbias, ldo/ldr %% 4 == 0");
   } else {
     VGEN_REQUIRE(a.epilogue == VGEN_EPI_NONE, "tapgemm: unknown epilogue");
+  }
+  if (a.colstats) {
+    VGEN_REQUIRE(a.out_dtype == VGEN_F32 && a.epilogue == VGEN_EPI_NONE && a.N % 4 == 0 && a.ldo % 4 == 0 &&
+                     (a.residual == nullptr || a.ldr % 4 == 0) && (a.rowbias == nullptr || a.rowbias_ld % 4 == 0) &&
+                     vgen_aligned16(a.colstats),
+                 "tapgemm: colstats needs fp32 output, no GEGLU, N/ldo/ldr/rowbias_ld %% 4 == 0");
   }
   hipStream_t s = (hipStream_t)stream;
   return a.dtype == VGEN_BF16 ? dispatch<BF16>(a, s) : dispatch<F16>(a, s);

@@ -11,6 +11,8 @@ does that, and a missing library / CPU tensor raises instead of falling back.
 """
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from dataclasses import dataclass, field
 from typing import Optional
@@ -20,6 +22,29 @@ import torch
 from . import lib as _lib
 
 _ENUM = {torch.bfloat16: _lib.VGEN_BF16, torch.float16: _lib.VGEN_F16, torch.float32: _lib.VGEN_F32}
+
+
+_COLSTATS_ON = os.environ.get("VGEN_COLSTATS", "1") != "0"   # tuning switch: 0 = GroupNorm always re-reads its input
+# Producers ask for statistics only where the launch is never split along K (the two exclude each other)
+# and the consuming GroupNorm streams from HBM instead of taking its single-launch path: M >= 8192 rows,
+# the 32x56 / 16x28 levels of the t2v UNet.
+COLSTATS_MIN_ROWS = int(os.environ.get("VGEN_COLSTATS_MIN_ROWS", "8192"))
+CS_ROWS = 64   # rows per column-statistics slab (include/vgen_hip.h: vgen_tapgemm_args.colstats)
+
+
+def colstats_of(t, rows):
+    """Statistics tensor [rows/64, 2, C] attached to `t` by the tap-GEMM that produced it, or None."""
+    cs = getattr(t, "vgen_cs", None)
+    if cs is None or t.dim() != 2 or not t.is_contiguous():
+        return None
+    if cs.shape != ((rows + CS_ROWS - 1) // CS_ROWS, 2, t.shape[1]) or t.shape[0] != rows:
+        return None
+    return cs
+
+
+def drop_colstats(t):
+    if hasattr(t, "vgen_cs"):
+        del t.vgen_cs
 
 
 @dataclass
@@ -52,6 +77,8 @@ class TapGemm:
     out_dtype: torch.dtype = torch.float32
     epilogue: int = _lib.EPI_NONE
     out: Optional[torch.Tensor] = None        # optional preallocated 2-D view [M, >=N_out]
+    colstats: bool = False                    # also emit per-64-row-slab column (sum, sumsq) of the fp32 output;
+                                              # attached to the returned tensor as `.vgen_cs` for groupnorm()
 
 
 @dataclass
@@ -129,11 +156,20 @@ class HipBackend:
         raw = torch.empty_like(y) if want_raw else None
         nbytes = self.lib.vgen_groupnorm_ws_bytes(nb, S)
         ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x1.device)
-        nbytes_moved = rows * (C1 + C2) * (4 + 4 + 2 + (2 if want_raw else 0))
+        # column statistics left behind by the producing tap-GEMMs (TapGemm.colstats)
+        cs1 = colstats_of(x1, rows)
+        cs2 = colstats_of(x2, rows) if x2 is not None else None
+        use_cs = S % CS_ROWS == 0 and cs1 is not None and (x2 is None or cs2 is not None)
+        nbytes_moved = rows * (C1 + C2) * ((4 if use_cs else 8) + 2 + (2 if want_raw else 0))
         with self._Prof("groupnorm", nbytes_moved, (nb, S, C1 + C2, int(want_raw))):
-            rc = self.lib.vgen_groupnorm(_ptr(x1), C1, _ptr(x2), C2, nb, S, groups, float(eps),
-                                         _ptr(gamma), _ptr(beta), int(bool(silu)), _ptr(y), _ptr(raw),
-                                         _ENUM[dt], _ptr(ws), nbytes, self._stream(x1))
+            if use_cs:
+                rc = self.lib.vgen_groupnorm_cs(_ptr(x1), C1, _ptr(cs1), _ptr(x2), C2, _ptr(cs2), nb, S, groups,
+                                                float(eps), _ptr(gamma), _ptr(beta), int(bool(silu)), _ptr(y),
+                                                _ptr(raw), _ENUM[dt], _ptr(ws), nbytes, self._stream(x1))
+            else:
+                rc = self.lib.vgen_groupnorm(_ptr(x1), C1, _ptr(x2), C2, nb, S, groups, float(eps),
+                                             _ptr(gamma), _ptr(beta), int(bool(silu)), _ptr(y), _ptr(raw),
+                                             _ENUM[dt], _ptr(ws), nbytes, self._stream(x1))
         _lib.check(rc, "vgen_groupnorm")
         return y, raw
 
@@ -181,6 +217,10 @@ class HipBackend:
             assert r.dtype == torch.float32 and r.shape[0] == g.M
             a.residual, a.ldr = r.data_ptr(), r.stride(0)
         a.out, a.ldo, a.out_dtype, a.epilogue = out.data_ptr(), out.stride(0), _ENUM[g.out_dtype], g.epilogue
+        cs = None
+        if g.colstats and _COLSTATS_ON:
+            cs = torch.empty(((g.M + CS_ROWS - 1) // CS_ROWS, 2, g.N), dtype=torch.float32, device=A.device)
+            a.colstats = cs.data_ptr()
         need = self.lib.vgen_tapgemm_ws_bytes(C.byref(a))
         if need:
             ws = torch.empty(need // 4, dtype=torch.float32, device=A.device)
@@ -189,6 +229,8 @@ class HipBackend:
                         (g.mode, g.M, g.N, g.taps * g.C1 + g.C2, g.epilogue, str(g.out_dtype))):
             rc = self.lib.vgen_tapgemm(C.byref(a), self._stream(A))
         _lib.check(rc, "vgen_tapgemm")
+        if cs is not None:
+            out.vgen_cs = cs
         return out
 
     # -- attention -------------------------------------------------------------------------
@@ -279,6 +321,7 @@ class HipBackend:
         assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 2
         rc = self.lib.vgen_scale_channels(_ptr(x), x.shape[0], x.shape[1], c0, c1, float(s), self._stream(x))
         _lib.check(rc, "vgen_scale_channels")
+        drop_colstats(x)           # modified in place: the producer's statistics no longer describe it
         return x
 
     def gauss_denoise(self, xt, y, u, guide, rescale, coef, pred_type, want_eps):

@@ -394,6 +394,7 @@ class UNetSD_T2VBase(nn.Module):
     # -- building blocks (all on the C ABI) ---------------------------------------------------
     def _linear(self, A, Wb, M, **kw):
         W, b = Wb if isinstance(Wb, tuple) else (Wb, None)
+        kw["colstats"] = kw.get("colstats", False) and M >= ops.COLSTATS_MIN_ROWS
         return ops.backend().tapgemm(TapGemm(A=A, W=W, M=M, N=W.shape[0], C1=A.shape[1], bias=b, **kw))
 
     def _conv3x3(self, A, Wb, nimg, Hi, Wi, C1, stride=1, ups=0, pad=(1, 1), crop=0, **kw):
@@ -401,6 +402,7 @@ class UNetSD_T2VBase(nn.Module):
         Hv, Wv = (Hi << ups) - 2 * crop, Wi << ups          # (virtual) conv input size
         Ho = (Hv + 2 * pad[0] - 3) // stride + 1
         Wo = (Wv + 2 * pad[1] - 3) // stride + 1
+        kw["colstats"] = kw.get("colstats", False) and nimg * Ho * Wo >= ops.COLSTATS_MIN_ROWS
         g = TapGemm(A=A, W=W, M=nimg * Ho * Wo, N=W.shape[0], C1=C1, mode=L.TAP_CONV3X3, taps=9,
                     Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo, stride=stride, pad_t=pad[0], pad_l=pad[1], ups=ups,
                     crop_t=crop, bias=b, **kw)
@@ -416,20 +418,24 @@ class UNetSD_T2VBase(nn.Module):
         has_skip = isinstance(rb.skip_connection, nn.Conv2d)
         a1, raw = be.groupnorm(x1, x2, B * F, S, 32, 1e-5, *P["gn1"], True, has_skip, dt)
         rowbias = emb_all[:, rb._emb_off: rb._emb_off + rb.cout]
-        h, _, _ = self._conv3x3(a1, P["conv1"], B * F, H, W, rb.cin, rowbias=rowbias, rows_per_rb=F * S)
+        # colstats=True: the conv epilogue leaves per-slab column sums behind, so the GroupNorm that
+        # consumes this tensor skips its statistics pass (every GN input of the UNet is a tap-GEMM output)
+        h, _, _ = self._conv3x3(a1, P["conv1"], B * F, H, W, rb.cin, rowbias=rowbias, rows_per_rb=F * S,
+                                colstats=True)
         a2, _ = be.groupnorm(h, None, B * F, S, 32, 1e-5, *P["gn2"], True, False, dt)
         if has_skip:
-            h, _, _ = self._conv3x3(a2, P["conv2"], B * F, H, W, rb.cout, A2=raw, C2=rb.cin)
+            h, _, _ = self._conv3x3(a2, P["conv2"], B * F, H, W, rb.cout, A2=raw, C2=rb.cin, colstats=True)
         else:
             assert x2 is None
-            h, _, _ = self._conv3x3(a2, P["conv2"], B * F, H, W, rb.cout, residual=x1)
+            h, _, _ = self._conv3x3(a2, P["conv2"], B * F, H, W, rb.cout, residual=x1, colstats=True)
         # temporal conv block: 4 x [GN over all frames + SiLU + Conv3d(3,1,1)] + identity
         t = h
         for i in (1, 2, 3, 4):
             a, _ = be.groupnorm(t, None, B, F * S, 32, 1e-5, *P[f"tgn{i}"], True, False, dt)
             Wt, bt = P[f"tconv{i}"]
             t = be.tapgemm(TapGemm(A=a, W=Wt, M=M, N=rb.cout, C1=rb.cout, mode=L.TAP_TEMPORAL3, taps=3,
-                                   F=F, S=S, bias=bt, residual=h if i == 4 else None))
+                                   F=F, S=S, bias=bt, residual=h if i == 4 else None,
+                                   colstats=M >= ops.COLSTATS_MIN_ROWS))
         return t
 
     def _tblock(self, P, x, M, d, heads, attn1, attn2):
@@ -480,7 +486,7 @@ class UNetSD_T2VBase(nn.Module):
                                      v_s=(kw, Lctx * kw, 0), o_s=(d, F * N * d, N * d), scale=scale))
 
         t = self._tblock(P["tb"], tok, M, d, heads, attn1, attn2)
-        return self._linear(t, P["pout"], M, residual=x)
+        return self._linear(t, P["pout"], M, residual=x, colstats=True)
 
     def _temporal_tx(self, tt: _TemporalTransformerP, x, B, F, H, W):
         """reference: TemporalTransformer.forward (util.py:1240-1286), only_self_att=True."""
@@ -506,7 +512,7 @@ class UNetSD_T2VBase(nn.Module):
             return self_attn(self._linear(n, P["tb"]["qkv2"], M, out_dtype=dt))
 
         t = self._tblock(P["tb"], tok, M, d, heads, self_attn, attn2)
-        return self._linear(t, P["pout"], M, residual=x)
+        return self._linear(t, P["pout"], M, residual=x, colstats=True)
 
     # -- forward -------------------------------------------------------------------------------
     @torch.no_grad()
@@ -565,7 +571,7 @@ class UNetSD_T2VBase(nn.Module):
             raise NotImplementedError("wide input stems are not on the t2v path")
         sFHW = F * H * W
         col = be.im2col3x3_small(x, B * F, F, C, H, W, (C * sFHW, H * W, sFHW, W, 1), self._kpad_in, dt)
-        h = self._linear(col, P["conv_in"], B * F * H * W)
+        h = self._linear(col, P["conv_in"], B * F * H * W, colstats=True)
 
         def run(mod, h, x2, H, W):
             if isinstance(mod, _ResBlockP):
@@ -577,11 +583,13 @@ class UNetSD_T2VBase(nn.Module):
                 return self._temporal_tx(mod, h, B, F, H, W), H, W
             if isinstance(mod, _DownP):
                 a = be.act_cast(h, 0, dt)
-                o, Ho, Wo = self._conv3x3(a, P[mod._pname], B * F, H, W, h.shape[1], stride=2, pad=mod.pad)
+                o, Ho, Wo = self._conv3x3(a, P[mod._pname], B * F, H, W, h.shape[1], stride=2, pad=mod.pad,
+                                          colstats=True)
                 return o, Ho, Wo
             if isinstance(mod, _UpP):
                 a = be.act_cast(h, 0, dt)
-                o, Ho, Wo = self._conv3x3(a, P[mod._pname], B * F, H, W, h.shape[1], ups=1, crop=mod.crop)
+                o, Ho, Wo = self._conv3x3(a, P[mod._pname], B * F, H, W, h.shape[1], ups=1, crop=mod.crop,
+                                          colstats=True)
                 return o, Ho, Wo
             raise TypeError(type(mod))
 
