@@ -54,7 +54,9 @@ __device__ __forceinline__ f32x4 gn_load(const float* x1, const float* x2, const
   return *(const f32x4*)(x2 + row * g.C2 + (c - g.C1));
 }
 
-// ws layout: part[nb][nsplit][groups][3] (count, mean, M2) then stat[nb][groups][2] (mean, rstd)
+// ws layout: part[nb][nsplit][groups][3] (count, mean, M2) then stat[nb][C][2]: per-channel
+// (scale, shift) = (gamma * rstd, beta - mean * gamma * rstd), written by the finalize kernels so that the
+// apply blocks start streaming after two coalesced loads instead of 16 dependent scalar ones
 __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(
     const float* __restrict__ x1, int C1, const float* __restrict__ x2, int C2, int64_t S,
     int groups, int nsplit, float* __restrict__ part) {
@@ -121,7 +123,9 @@ __global__ __launch_bounds__(GN_THREADS) void gn_stats_kernel(
 }
 
 __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict__ part,
-                                                         int groups, int nsplit, float eps,
+                                                         int groups, int nsplit, float eps, int C,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta,
                                                          float* __restrict__ stat) {
   // one wave per (batch, group): lane j Chan-folds splits j, j+64, ... (<= 16 each), then a 6-step
   // butterfly.  (The first version used 8 lanes per group in one block per batch: up to 128
@@ -157,10 +161,14 @@ __global__ __launch_bounds__(64) void gn_finalize_kernel(const float* __restrict
     }
     n = nt;
   }
-  if (lane == 0) {
-    const float var = n > 0.f ? m2 / n : 0.f;
-    stat[(nb * groups + grp) * 2 + 0] = mean;
-    stat[(nb * groups + grp) * 2 + 1] = 1.0f / sqrtf(var + eps);
+  // the symmetric butterfly leaves identical (n, mean, m2) in every lane
+  const float rstd = 1.0f / sqrtf((n > 0.f ? m2 / n : 0.f) + eps);
+  const int cpg = C / groups;
+  for (int j = lane; j < cpg; j += 64) {
+    const int c = grp * cpg + j;
+    const float a = gamma[c] * rstd;
+    stat[(nb * C + c) * 2 + 0] = a;
+    stat[(nb * C + c) * 2 + 1] = beta[c] - mean * a;
   }
 }
 
@@ -183,8 +191,11 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, flo
 __global__ __launch_bounds__(256) void gn_finalize_cs_kernel(const float* __restrict__ cs1, int C1,
                                                              const float* __restrict__ cs2, int C2,
                                                              int64_t S, int groups, float eps,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
                                                              float* __restrict__ stat) {
   __shared__ float red[4][3];
+  __shared__ float mr[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int grp = blockIdx.x;
   const int64_t nb = blockIdx.y;
@@ -248,8 +259,16 @@ __global__ __launch_bounds__(256) void gn_finalize_cs_kernel(const float* __rest
     float N = red[0][0], M = red[0][1], Q = red[0][2];
     for (int k = 1; k < 4; ++k) chan_merge(N, M, Q, red[k][0], red[k][1], red[k][2]);
     const float var = N > 0.f ? Q / N : 0.f;
-    stat[(nb * groups + grp) * 2 + 0] = M;
-    stat[(nb * groups + grp) * 2 + 1] = 1.0f / sqrtf(var + eps);
+    mr[0] = M;
+    mr[1] = 1.0f / sqrtf(var + eps);
+  }
+  __syncthreads();
+  const int C = C1 + C2;
+  for (int j = tid; j < cpg; j += 256) {
+    const int c = grp * cpg + j;
+    const float a = gamma[c] * mr[1];
+    stat[(nb * C + c) * 2 + 0] = a;
+    stat[(nb * C + c) * 2 + 1] = beta[c] - mr[0] * a;
   }
 }
 
@@ -275,17 +294,51 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(
   for (int k = 0; k < GN_MAX_SLOTS; ++k) {
     const int slot = slot0 + k * GN_THREADS;
     if (k < g.spt && slot < g.nslots) {
+      const f32x4 p0 = *(const f32x4*)(stat + (nb * g.C + slot * 4) * 2);       // a0 b0 a1 b1
+      const f32x4 p1 = *(const f32x4*)(stat + (nb * g.C + slot * 4) * 2 + 4);   // a2 b2 a3 b3
+      sc[k] = f32x4{p0.x, p0.z, p1.x, p1.z};
+      sh[k] = f32x4{p0.y, p0.w, p1.y, p1.w};
+    }
+  }
+  if (g.spt == 1) {
+    // one 16-byte slot per thread and row (C <= 1024, every UNet width): explicit register double
+    // buffer, U rows per thread in flight while the previous U are normalised and stored
+    constexpr int U = 4;
+    const int c = slot0 * 4;
+    const bool from1 = c < g.C1;
+    const float* src = from1 ? x1 + c : x2 + (c - g.C1);
+    const int64_t ld = from1 ? g.C1 : g.C2;
+    f32x4 cur[U], nxt[U];
+    int64_t r = r_begin + rowlane;
+    auto load = [&](int64_t r0, f32x4* dst) __attribute__((always_inline)) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int c = slot * 4 + e;
-        const int grp = c / g.cpg;
-        const float mean = stat[(nb * groups + grp) * 2 + 0];
-        const float rstd = stat[(nb * groups + grp) * 2 + 1];
-        const float a = gamma[c] * rstd;
-        sc[k][e] = a;
-        sh[k][e] = beta[c] - mean * a;
+      for (int u = 0; u < U; ++u) {
+        const int64_t rr = r0 + (int64_t)u * g.rpb;
+        const int64_t row = nb * S + (rr < r_end ? rr : r_end - 1);     // clamped rows are never stored
+        dst[u] = *(const f32x4*)(src + row * ld);
+      }
+    };
+    if (r < r_end) load(r, nxt);
+    for (; r < r_end; r += (int64_t)U * g.rpb) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+      if (r + (int64_t)U * g.rpb < r_end) load(r + (int64_t)U * g.rpb, nxt);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t rr = r + (int64_t)u * g.rpb;
+        if (rr < r_end) {
+          const int64_t row = nb * S + rr;
+          f32x4 o = cur[u] * sc[0] + sh[0];
+          if (silu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = silu_f(o[e]);
+          }
+          *(u32x2*)(y + row * g.C + c) = pack4<T>(o.x, o.y, o.z, o.w);
+          if (raw) *(u32x2*)(raw + row * g.C + c) = pack4<T>(cur[u].x, cur[u].y, cur[u].z, cur[u].w);
+        }
       }
     }
+    return;
   }
 #pragma unroll 4
   for (int64_t r = r_begin + rowlane; r < r_end; r += g.rpb) {
@@ -563,7 +616,7 @@ void dispatch_ln(const float* x, int64_t M, int d, float eps, const float* gamma
 
 extern "C" size_t vgen_groupnorm_ws_bytes(int64_t nb, int64_t S) {
   const int ns = 1024;   // upper bound of gn_nsplit (independent of C so callers need not pass it)
-  return (size_t)(nb * ns * GN_G * 3 + nb * GN_G * 2) * sizeof(float);
+  return (size_t)(nb * ns * GN_G * 3 + nb * 3072 * 2) * sizeof(float);   // partials + per-channel (scale, shift)
 }
 
 static int groupnorm_impl(const float* x1, int32_t C1, const float* cs1, const float* x2, int32_t C2,
@@ -632,7 +685,7 @@ static int groupnorm_impl(const float* x1, int32_t C1, const float* cs1, const f
   int rc;
   if (cs1 != nullptr) {
     hipLaunchKernelGGL(gn_finalize_cs_kernel, dim3((unsigned)groups, (unsigned)nb), dim3(256), 0, s, cs1, C1,
-                       cs2, C2, S, groups, eps, stat);
+                       cs2, C2, S, groups, eps, gamma, beta, stat);
     rc = vgen_check_launch("gn_finalize_cs");
     if (rc) return rc;
   } else {
@@ -641,7 +694,7 @@ static int groupnorm_impl(const float* x1, int32_t C1, const float* cs1, const f
     rc = vgen_check_launch("gn_stats");
     if (rc) return rc;
     hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)groups, (unsigned)nb), dim3(64), 0, s, part,
-                       groups, ns, eps, stat);
+                       groups, ns, eps, C, gamma, beta, stat);
     rc = vgen_check_launch("gn_finalize");
     if (rc) return rc;
   }
