@@ -72,6 +72,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--partition", action="store_true",
+                    help="use the multi-GPU code path (UnitPartition + graphed local forward + eager gather/update) "
+                         "even at --gpus 1")
     ap.add_argument("--dump-shapes", action="store_true", help="write per-shape tap-GEMM timings to gpurun_out/")
     args = ap.parse_args()
 
@@ -111,17 +114,22 @@ def main():
     y_u = torch.randn(P, 77, 1024, generator=g, device=dev)
     kw = [dict(y=y_c), dict(y=y_u)]
     steps_all = (1 + torch.arange(0, 1000, 20)).clamp(0, 999).flip(0).tolist()
-    part = UnitPartition() if world > 1 else None
+    part = UnitPartition() if (world > 1 or args.partition) else None
     diff.partition = part
+    step_model = model
+    if part is not None and not args.no_graph:
+        # the RCCL all-gather stays outside the graph: replay the local units' forward, then gather + update
+        from vgen_amd.graph import GraphedForward
+        step_model = GraphedForward(model, warmup=1)
 
     state = {"xt": xt}
     t_buf = torch.full((P,), steps_all[0], dtype=torch.long, device=dev)
 
     def one_step():
-        state["xt"], _ = diff.ddim_sample(state["xt"], t_buf, model, kw, guide_scale=9.0,
+        state["xt"], _ = diff.ddim_sample(state["xt"], t_buf, step_model, kw, guide_scale=9.0,
                                           ddim_timesteps=50, eta=0.0)
 
-    use_graph = (not args.no_graph) and world == 1
+    use_graph = (not args.no_graph) and part is None
     graph = None
     static_in = None
     if use_graph:
@@ -144,6 +152,11 @@ def main():
 
     def set_t(i):
         t_buf.fill_(steps_all[i % len(steps_all)])
+
+    if step_model is not model:      # untimed: eager pass + capture of the local forward (like the N=1 capture above)
+        for _ in range(2):
+            one_step()
+        state["xt"] = xt
 
     for i in range(args.warmup):
         set_t(i)
@@ -177,7 +190,7 @@ def main():
                                "+ fused update), guide 9, 77x1024 ctx, random-init 1411M params",
                    "prompts_in_flight": P, "units_per_step": 2 * P,
                    "parallelism": "single GPU" if world == 1 else f"unit partition over {world} ranks, 1 all-gather/step",
-                   "hipgraph": bool(use_graph)},
+                   "hipgraph": "whole step" if use_graph else ("local forward" if step_model is not model else False)},
         "finite": finite,
         "model_tflops_per_s": round(2 * UNET_FWD_TFLOP * steps_per_s, 2),
     }
