@@ -244,6 +244,13 @@ def main():
                            "avg_launch_us": round(1e3 * tot_ms / max(len(recs), 1), 2),
                            "avg_gflop_per_launch": round(tot_fl / max(len(recs), 1) / 1e9, 3),
                            "tapgemm_ms_per_step": round(tot_ms, 3)}
+        # HBM-side bytes per launch cannot be read from inside the process: they come from the committed
+        # rocprofv3 PMC passes of this same command (tools/collect_evidence.sh -> profiles/)
+        tpath = os.path.join(ROOT, "profiles", "r01_tapgemm_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            res["roofline"]["traffic"] = round(tj["hbm_bytes_per_launch"])
+            res["roofline"]["traffic_unit"] = "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/r01_tapgemm_traffic.json)"
 
     # ---- VAE decode frames/s ---------------------------------------------------------------------------
     if rank == 0 and not args.no_vae:
