@@ -58,13 +58,47 @@ def dummy_model(x, t, y=None, **kw):
         + 0.001 * t.float().view(-1, 1, 1, 1, 1)
 
 
+I2V_TINY = dict(in_dim=4, dim=64, y_dim=1024, context_dim=1024, concat_dim=4, out_dim=4, dim_mult=[1, 2, 4],
+                num_heads=2, head_dim=64, num_res_blocks=1, attn_scales=[1.0, 0.5, 0.25], dropout=0.1,
+                temporal_attention=True, temporal_attn_times=1, use_checkpoint=False, use_fps_condition=False,
+                use_sim_mask=False, training=False)
+
+
+def make_i2vgen(R):
+    """tiny UNetSD_I2VGen: local-image concat branch, 64 local + 4 global image tokens, fps embedding."""
+    ref = R["MODEL"].build(dict(type="UNetSD_I2VGen", **I2V_TINY)).eval()
+    shapes = torch_ref.shapes_of(ref)
+    ref.load_state_dict(torch_ref.synth_state_dict(shapes, seed=4), strict=True)
+    g = torch.Generator("cpu").manual_seed(11)
+    x = torch.randn(2, 4, 4, 16, 8, generator=g)
+    y = torch.randn(2, 77, 1024, generator=g)
+    image = torch.randn(2, 1, 1024, generator=g)
+    local_image = torch.randn(2, 4, 16, 8, generator=g)
+    fps = torch.tensor([8, 16])
+    t = torch.tensor([981, 401])
+    _cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self           # mask_pos hard-codes .cuda() (unet_i2vgen.py:284)
+    try:
+        with torch.no_grad():
+            out = ref(x, t, y=y, image=image, local_image=local_image, fps=fps)
+    finally:
+        torch.Tensor.cuda = _cuda
+    torch.save(dict(cfg=I2V_TINY, seed=4, shapes=shapes, x=x, t=t, y=y, image=image, local_image=local_image,
+                    fps=fps, out=out), os.path.join(GOLD, "unet_i2vgen_tiny.pt"))
+    print("unet_i2vgen_tiny", tuple(out.shape), float(out.std()))
+
+
 @torch.no_grad()
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
+    ap.add_argument("--only", default=None, help="regenerate a single fixture family (i2vgen)")
     args = ap.parse_args()
     os.makedirs(GOLD, exist_ok=True)
     R = ref_import.load()
+    if args.only == "i2vgen":
+        make_i2vgen(R)
+        return
     torch.manual_seed(0)
 
     # ---- schedules + sampler --------------------------------------------------------------
@@ -146,6 +180,7 @@ def main():
     torch.save(dict(cfg=SR_TINY, seed=3, shapes=srshapes, x=xsr, t=tsr, y=ysr, out=osr),
                os.path.join(GOLD, "unet_sr600_tiny.pt"))
     print("unet_sr600_tiny", tuple(osr.shape), float(osr.std()))
+    make_i2vgen(R)
 
     # ---- tiny VAE ------------------------------------------------------------------------------
     vae = R["AUTO_ENCODER"].build(dict(type="AutoencoderKL", ddconfig=VAE_TINY, embed_dim=4)).eval()

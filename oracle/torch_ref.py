@@ -184,12 +184,64 @@ def unet_sr600_forward(sd, x, t, y, dim):
     return unet_forward(sd, x, t, y, dim, down_padding=(2, 1), up_crop=1, freeu=((1.1, 0.6), (1.2, 0.4)))
 
 
-def unet_forward(sd, x, t, y, dim, down_padding=1, up_crop=0, freeu=None):
-    """UNetSD_T2VBase.forward / _forward_single, unet/unet_t2v.py:210-348 (use_fps_condition
-    False, y given).  The block structure is recovered from the state_dict keys."""
+def i2vgen_stems(sd, local_image, image, b, f, h, w, num_tokens, context_dim):
+    """UNetSD_I2VGen condition stems, unet_i2vgen.py:262-265 (first frame of the local image),
+    :280-295 (local-image map: conv stack -> one TransformerV2 layer over frames, added TWICE into the
+    concat buffer), :310-321 (64 local-image tokens from the pooled conv pyramid, num_tokens global tokens)."""
+    li = local_image[:, :, :1] if local_image.dim() == 5 else local_image.unsqueeze(2)
+    frames = [li] + [torch.ones_like(li) * ((tp + 1) / (f - 1)) for tp in range(f - 1)]
+    xi = torch.cat(frames, 2).permute(0, 2, 1, 3, 4).reshape(b * f, li.shape[1], h, w)
+    p = "local_image_concat"
+    xi = F.conv2d(xi, sd[p + ".0.weight"], sd[p + ".0.bias"], padding=1)
+    xi = F.conv2d(F.silu(xi), sd[p + ".2.weight"], sd[p + ".2.bias"], padding=1)
+    xi = F.conv2d(F.silu(xi), sd[p + ".4.weight"], sd[p + ".4.bias"], padding=1)
+    cc = xi.shape[1]
+    s = xi.reshape(b, f, cc, h, w).permute(0, 3, 4, 1, 2).reshape(b * h * w, f, cc)
+    j = 0
+    while f"local_temporal_encoder.layers.{j}.0.norm.weight" in sd:      # TransformerV2, util.py:1434-1453
+        q = f"local_temporal_encoder.layers.{j}"
+        n = F.layer_norm(s, (cc,), sd[q + ".0.norm.weight"], sd[q + ".0.norm.bias"])
+        qkv = F.linear(n, sd[q + ".0.fn.to_qkv.weight"])
+        inner = qkv.shape[-1] // 3
+        heads = 2
+        qh, kh, vh = [u.reshape(b * h * w, f, heads, inner // heads).transpose(1, 2) for u in qkv.split(inner, -1)]
+        att = torch.softmax(qh @ kh.transpose(-1, -2) * (inner // heads) ** -0.5, -1) @ vh
+        att = att.transpose(1, 2).reshape(b * h * w, f, inner)
+        s = F.linear(att, sd[q + ".0.fn.to_out.0.weight"], sd[q + ".0.fn.to_out.0.bias"]) + s
+        m = F.gelu(F.linear(s, sd[q + ".1.net.0.0.weight"], sd[q + ".1.net.0.0.bias"]))
+        s = F.linear(m, sd[q + ".1.net.2.weight"], sd[q + ".1.net.2.bias"]) + s
+        j += 1
+    concat = 2.0 * s.reshape(b, h, w, f, cc).permute(0, 4, 3, 1, 2)
+    p = "local_image_embedding"
+    lc = F.silu(F.conv2d(li[:, :, 0], sd[p + ".0.weight"], sd[p + ".0.bias"], padding=1))
+    lc = F.adaptive_avg_pool2d(lc, (32, 32))
+    lc = F.silu(F.conv2d(lc, sd[p + ".3.weight"], sd[p + ".3.bias"], stride=2, padding=1))
+    lc = F.conv2d(lc, sd[p + ".5.weight"], sd[p + ".5.bias"], stride=2, padding=1)
+    extra = lc.flatten(2).transpose(1, 2)
+    if image is not None:
+        ic = F.linear(F.silu(F.linear(image, sd["context_embedding.0.weight"], sd["context_embedding.0.bias"])),
+                      sd["context_embedding.2.weight"], sd["context_embedding.2.bias"])
+        extra = torch.cat([extra, ic.reshape(-1, num_tokens, context_dim)], 1)
+    return concat, extra
+
+
+def unet_i2vgen_forward(sd, x, t, y, image, local_image, fps, dim, num_tokens=4, context_dim=1024):
+    """UNetSD_I2VGen.forward, unet_i2vgen.py:243-346: stems, then the shared trunk on cat([x, concat]) with
+    context = text | local-image | global-image tokens."""
+    b, c, f, h, w = x.shape
+    concat, extra = i2vgen_stems(sd, local_image, image, b, f, h, w, num_tokens, context_dim)
+    return unet_forward(sd, torch.cat([x, concat], 1), t, torch.cat([y, extra], 1), dim, fps=fps)
+
+
+def unet_forward(sd, x, t, y, dim, down_padding=1, up_crop=0, freeu=None, fps=None):
+    """UNetSD_T2VBase.forward / _forward_single, unet/unet_t2v.py:210-348 (y given; `fps` adds the
+    fps embedding, :244-245 / unet_i2vgen.py:298).  The block structure is recovered from the state_dict keys."""
     b, c, f, h, w = x.shape
     emb = F.linear(sinusoidal_embedding(t, dim), sd["time_embed.0.weight"], sd["time_embed.0.bias"])
     emb = F.linear(F.silu(emb), sd["time_embed.2.weight"], sd["time_embed.2.bias"])
+    if fps is not None:
+        e2 = F.linear(sinusoidal_embedding(fps, dim), sd["fps_embedding.0.weight"], sd["fps_embedding.0.bias"])
+        emb = emb + F.linear(F.silu(e2), sd["fps_embedding.2.weight"], sd["fps_embedding.2.bias"])
     emb = emb.repeat_interleave(repeats=f, dim=0)
     context = y.repeat_interleave(repeats=f, dim=0)
     x = x.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)

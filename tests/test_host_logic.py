@@ -155,3 +155,30 @@ def test_sr600_oracle_and_host_logic_vs_reference_golden(emu_backend):
     m.load_state_dict(sd, strict=True)
     out = m(g["x"], g["t"], g["y"], x_lr=None)
     assert out.shape == g["out"].shape and rel_l2(out, g["out"]) < 3e-3
+
+
+# ---- UNetSD_I2VGen (trunk variant with condition stems) -------------------------------
+def test_i2vgen_oracle_and_host_logic_vs_reference_golden(emu_backend):
+    from vgen_amd.unet_i2vgen import UNetSD_I2VGen
+    g = gold("unet_i2vgen_tiny.pt")
+    sd = torch_ref.synth_state_dict(g["shapes"], seed=g["seed"])
+    ref = torch_ref.unet_i2vgen_forward(sd, g["x"], g["t"], g["y"], g["image"], g["local_image"], g["fps"],
+                                        g["cfg"]["dim"])
+    assert rel_l2(ref, g["out"]) < 2e-5                      # the restatement is pinned to the reference's output
+    m = UNetSD_I2VGen(**g["cfg"], compute_dtype="fp16").eval()
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v) for k, v in g["shapes"].items()}
+    m.load_state_dict(sd, strict=True)
+    kw = dict(y=g["y"], image=g["image"], local_image=g["local_image"], fps=g["fps"])
+    out = m(g["x"], g["t"], **kw)
+    assert out.shape == g["out"].shape and rel_l2(out, g["out"]) < 3e-3
+    # stems are prompt constants: cached per conditioning input, recomputed when it changes
+    c0 = m._stem_cache[1][0]
+    m(g["x"] * 0.5, g["t"], **kw)
+    assert m._stem_cache[1][0] is c0
+    li2 = g["local_image"] * 1.5
+    m(g["x"], g["t"], y=g["y"], image=g["image"], local_image=li2, fps=g["fps"])
+    assert m._stem_cache[1][0] is not c0
+    # CFG pair as one batch == two calls
+    kw2 = dict(kw, y=torch.roll(g["y"], 1, 1))
+    a, b = m.forward_units(g["x"], g["t"], [kw, kw2])
+    assert rel_l2(a, m(g["x"], g["t"], **kw)) < 1e-5 and rel_l2(b, m(g["x"], g["t"], **kw2)) < 1e-5

@@ -16,6 +16,9 @@ def test_native_registries_resolve_reference_names():
                                      var_type="fixed_small", noise_strength=0.1))
     assert d.num_timesteps == 100 and type(d).__module__ == "vgen_amd.diffusion"
     assert regs["MODEL"].get("UNetSD_T2VBase").__module__ == "vgen_amd.unet"
+    assert regs["MODEL"].get("UNetSD_SR600").__module__ == "vgen_amd.unet"
+    assert regs["MODEL"].get("UNetSD_I2VGen").__module__ == "vgen_amd.unet_i2vgen"
+    assert regs["DIFFUSION"].get("DiffusionDDIMSR").__module__ == "vgen_amd.diffusion_gauss"
     assert regs["AUTO_ENCODER"].get("AutoencoderKL").__module__ == "vgen_amd.vae"
 
 
@@ -57,8 +60,9 @@ def test_extra_kwargs_and_unknown_cfg_keys_are_accepted():
 def test_install_overrides_the_reference_registries_in_place():
     from oracle import ref_import
     R = ref_import.load()
-    orig = {k: R[k].get(n) for k, n in (("MODEL", "UNetSD_T2VBase"), ("AUTO_ENCODER", "AutoencoderKL"),
-                                         ("DIFFUSION", "DiffusionDDIM"))}
+    names = (("MODEL", "UNetSD_T2VBase"), ("MODEL", "UNetSD_SR600"), ("MODEL", "UNetSD_I2VGen"),
+             ("AUTO_ENCODER", "AutoencoderKL"), ("DIFFUSION", "DiffusionDDIM"), ("DIFFUSION", "DiffusionDDIMSR"))
+    orig = {(k, n): R[k].get(n) for k, n in names}
     try:
         regs = vgen_amd.install()
         assert regs["MODEL"] is R["MODEL"]
@@ -71,6 +75,5 @@ def test_install_overrides_the_reference_registries_in_place():
     finally:
         with warnings.catch_warnings():
             warnings.simplefilter("ignore")
-            R["MODEL"].register_class("UNetSD_T2VBase")(orig["MODEL"])
-            R["AUTO_ENCODER"].register_class("AutoencoderKL")(orig["AUTO_ENCODER"])
-            R["DIFFUSION"].register_class("DiffusionDDIM")(orig["DIFFUSION"])
+            for (k, n), cls in orig.items():
+                R[k].register_class(n)(cls)

@@ -98,8 +98,9 @@ def _native_classes():
     from .diffusion import DiffusionDDIM
     from .diffusion_gauss import DiffusionDDIMSR
     from .unet import UNetSD_SR600, UNetSD_T2VBase
+    from .unet_i2vgen import UNetSD_I2VGen
     from .vae import AutoencoderKL
-    return {"MODEL": [UNetSD_T2VBase, UNetSD_SR600], "AUTO_ENCODER": [AutoencoderKL],
+    return {"MODEL": [UNetSD_T2VBase, UNetSD_SR600, UNetSD_I2VGen], "AUTO_ENCODER": [AutoencoderKL],
             "DIFFUSION": [DiffusionDDIM, DiffusionDDIMSR]}
 
 

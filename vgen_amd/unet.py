@@ -183,6 +183,10 @@ def _f32(t):
 class UNetSD_T2VBase(nn.Module):
     _down_padding = 1          # Downsample conv padding (SR600: (2, 1))
     _up_crop = 0               # rows cropped after the nearest-2x upsample (SR600: 1)
+    @staticmethod
+    def _extra_stem_channels(kwargs):
+        return 0               # UNetSD_I2VGen: + concat_dim channels of the local-image branch
+
     _freeu = None              # SR600: ((backbone boost, skip low-frequency scale), ...) for decoder blocks 0, 1
 
     def __init__(self, config=None, in_dim=4, dim=512, y_dim=512, context_dim=512, hist_dim=156,
@@ -223,7 +227,7 @@ class UNetSD_T2VBase(nn.Module):
 
         # encoder (block order as unet_t2v.py:110-148)
         self.input_blocks = nn.ModuleList()
-        self.input_blocks.append(nn.ModuleList([nn.Conv2d(in_dim, dim, 3, padding=1),
+        self.input_blocks.append(nn.ModuleList([nn.Conv2d(in_dim + self._extra_stem_channels(kwargs), dim, 3, padding=1),
                                                 _TemporalTransformerP(dim, num_heads)]))
         shortcut_dims.append(dim)
         for i, (cin, cout) in enumerate(zip(enc_dims[:-1], enc_dims[1:])):
@@ -262,6 +266,9 @@ class UNetSD_T2VBase(nn.Module):
         nn.init.zeros_(self.out[-1].weight)
 
         self._packed = None
+
+    def _stem_channels(self):
+        return self.input_blocks[0][0].in_channels
 
     # -- packing -----------------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
@@ -321,12 +328,13 @@ class UNetSD_T2VBase(nn.Module):
         P["kv_width"] = off
 
         conv_in = self.input_blocks[0][0]
-        self._kpad_in = ((9 * self.in_dim + 63) // 64) * 64
-        if self.in_dim % 64 == 0:
+        cin0 = self._stem_channels()
+        self._kpad_in = ((9 * cin0 + 63) // 64) * 64
+        if cin0 % 64 == 0:
             P["conv_in"] = (pack_conv3x3(conv_in.weight, dt), _f32(conv_in.bias))
         else:
-            if self.in_dim > 16:
-                raise NotImplementedError("in_dim must be <= 16 or a multiple of 64")
+            if cin0 > 16:
+                raise NotImplementedError("stem conv input channels must be <= 16 or a multiple of 64")
             P["conv_in"] = (pack_small_conv3x3(conv_in.weight, self._kpad_in, dt), _f32(conv_in.bias))
 
         def pack_res(rb: _ResBlockP):
@@ -534,13 +542,20 @@ class UNetSD_T2VBase(nn.Module):
     @torch.no_grad()
     def forward(self, x, t, y=None, fps=None, masked=None, video_mask=None, focus_present_mask=None,
                 prob_focus_present=0., mask_last_frame_num=0, **kwargs):
+        # [Context]  unet_t2v.py:247-255 (no per-frame repeat: K/V are indexed per prompt)
+        ctx = y if y is not None else self.zero_y.repeat(x.shape[0], 1, 1)[:, :1, :]
+        return self._trunk(x, t, ctx, fps)
+
+    def _trunk(self, x, t, ctx, fps=None):
+        """Embeddings + encoder / middle / decoder / head on rows (unet_t2v.py:241-277).  `x` carries every
+        input channel of the stem conv ([B, C, F, H, W]), `ctx` every cross-attention token ([B, L, 1024])."""
         be = ops.backend()
         dt = self.compute_dtype
         if self._packed is None:
             self.pack()
         P = self._packed
         B, C, F, H, W = x.shape
-        assert C == self.in_dim
+        assert C == self._stem_channels()
         dev = x.device
         x = x.float().contiguous()
 
@@ -557,17 +572,12 @@ class UNetSD_T2VBase(nn.Module):
         es = be.act_cast(e, 1, dt)                                  # emb_layers[0] = SiLU
         emb_all = self._linear(es, P["emb_all"], B)                 # [B, sum(Cout)] fp32
 
-        # [Context]  unet_t2v.py:247-255 (no per-frame repeat: K/V are indexed per prompt)
-        if y is not None:
-            ctx = y
-        else:
-            ctx = self.zero_y.repeat(B, 1, 1)[:, :1, :]
         Lctx = ctx.shape[1]
         ctx16 = be.act_cast(ctx.to(device=dev, dtype=torch.float32).reshape(B * Lctx, -1).contiguous(), 0, dt)
         kv_all = self._linear(ctx16, P["kv_all"], B * Lctx, out_dtype=dt)
 
         # input conv: im2col of the [B,C,F,H,W] latent straight into rows
-        if self.in_dim % 64 == 0:
+        if C % 64 == 0:
             raise NotImplementedError("wide input stems are not on the t2v path")
         sFHW = F * H * W
         col = be.im2col3x3_small(x, B * F, F, C, H, W, (C * sFHW, H * W, sFHW, W, 1), self._kpad_in, dt)

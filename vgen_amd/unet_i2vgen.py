@@ -1,0 +1,178 @@
+"""UNetSD_I2VGen drop-in (reference: tools/modules/unet/unet_i2vgen.py:20-346).
+
+The trunk — time/fps embedding, encoder / middle / decoder of ResBlock + temporal conv, Spatial and
+Temporal transformers, head — is the t2v trunk (`UNetSD_T2VBase._trunk`, all hand-written HIP); the
+differences are the stem conv's extra `concat_dim` input channels and the longer cross-attention
+context (77 text tokens + 64 local-image tokens + `num_tokens` global-image tokens).
+
+The condition stems that produce those extras depend only on the conditioning image, not on x or t:
+the reference recomputes them on every denoise step (unet_i2vgen.py:280-321), here they are evaluated
+once per conditioning input and cached.  They are tiny (4..64-channel convs, an 8x8-token pooling
+pyramid, a 4-wide one-layer transformer over frames) and run through plain torch modules on the
+device — prompt-constant plumbing ahead of the hot path (SURVEY §8 f2 lists native stems as "next").
+Parameter names / shapes equal the reference's, so stock checkpoints load strict.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F_
+
+from .unet import UNetSD_T2VBase
+
+
+class _FrameAttention(nn.Module):
+    """util.py:1396-1424 — multi-head softmax attention over the frame axis, bias-free qkv."""
+
+    def __init__(self, dim, heads, dim_head):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads = heads
+        self.to_qkv = nn.Linear(dim, 3 * inner, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, dim)) if not (heads == 1 and dim_head == dim) else nn.Identity()
+
+    def forward(self, x):                                   # [n, f, dim]
+        n, f, _ = x.shape
+        q, k, v = self.to_qkv(x).view(n, f, 3, self.heads, -1).permute(2, 0, 3, 1, 4)
+        o = F_.scaled_dot_product_attention(q, k, v)        # scale = dim_head ** -0.5
+        return self.to_out(o.transpose(1, 2).reshape(n, f, -1))
+
+
+class _PreNorm(nn.Module):
+    """util.py:1426-1432."""
+
+    def __init__(self, dim, fn):
+        super().__init__()
+        self.norm = nn.LayerNorm(dim)
+        self.fn = fn
+
+    def forward(self, x):
+        return self.fn(self.norm(x)) + x
+
+
+class _MLP(nn.Module):
+    """util.py:724-741 with glu=False: Linear -> GELU -> Linear (parameter paths net.0.0 / net.2)."""
+
+    def __init__(self, dim, dim_out, mult=4):
+        super().__init__()
+        self.net = nn.Sequential(nn.Sequential(nn.Linear(dim, dim * mult), nn.GELU()), nn.Identity(),
+                                 nn.Linear(dim * mult, dim_out))
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class _FrameTransformer(nn.Module):
+    """util.py:1434-1453 (TransformerV2)."""
+
+    def __init__(self, heads, dim, dim_head, mlp_dim, depth):
+        super().__init__()
+        self.layers = nn.ModuleList([nn.ModuleList([_PreNorm(dim, _FrameAttention(dim, heads, dim_head)),
+                                                    _MLP(dim, mlp_dim)]) for _ in range(depth)])
+
+    def forward(self, x):
+        for attn, ff in self.layers:
+            x = attn(x)
+            x = ff(x) + x
+        return x
+
+
+class UNetSD_I2VGen(UNetSD_T2VBase):
+    @staticmethod
+    def _extra_stem_channels(kwargs):
+        return kwargs["_i2v_concat"]
+
+    def __init__(self, config=None, in_dim=7, dim=512, y_dim=512, context_dim=512, hist_dim=156, concat_dim=8,
+                 dim_condition=4, out_dim=6, num_tokens=4, dim_mult=[1, 2, 3, 4], num_heads=None, head_dim=64,
+                 num_res_blocks=3, attn_scales=[1 / 2, 1 / 4, 1 / 8], use_scale_shift_norm=True, dropout=0.1,
+                 temporal_attn_times=1, temporal_attention=True, use_checkpoint=False, use_image_dataset=False,
+                 use_sim_mask=False, training=True, inpainting=True, p_all_zero=0.1, p_all_keep=0.1, zero_y=None,
+                 adapter_transformer_layers=1, compute_dtype=None, **kwargs):
+        kwargs.pop("use_fps_condition", None)            # yaml carries it; the fps embedding is unconditional here
+        cc = in_dim                                      # unet_i2vgen.py:81: the stems use in_dim channels
+        super().__init__(config=config, in_dim=in_dim, dim=dim, y_dim=y_dim, context_dim=context_dim,
+                         hist_dim=hist_dim, dim_condition=dim_condition, out_dim=out_dim, num_tokens=num_tokens,
+                         dim_mult=dim_mult, num_heads=num_heads, head_dim=head_dim, num_res_blocks=num_res_blocks,
+                         attn_scales=attn_scales, use_scale_shift_norm=use_scale_shift_norm, dropout=dropout,
+                         temporal_attn_times=temporal_attn_times, temporal_attention=temporal_attention,
+                         use_checkpoint=use_checkpoint, use_image_dataset=use_image_dataset, use_sim_mask=use_sim_mask,
+                         training=training, inpainting=inpainting, use_fps_condition=True, p_all_zero=p_all_zero,
+                         p_all_keep=p_all_keep, zero_y=zero_y, adapter_transformer_layers=adapter_transformer_layers,
+                         compute_dtype=compute_dtype, _i2v_concat=cc, **kwargs)
+        if concat_dim != in_dim:
+            raise ValueError("UNetSD_I2VGen: concat_dim must equal in_dim (the reference adds an in_dim-channel "
+                             "local-image map into a concat_dim-channel buffer, unet_i2vgen.py:81,281-295)")
+        self.concat_dim, self.num_tokens = concat_dim, num_tokens
+        embed_dim = dim * 4
+        self.context_embedding = nn.Sequential(nn.Linear(y_dim, embed_dim), nn.SiLU(),
+                                               nn.Linear(embed_dim, context_dim * num_tokens))
+        self.local_image_concat = nn.Sequential(nn.Conv2d(4, cc * 4, 3, padding=1), nn.SiLU(),
+                                                nn.Conv2d(cc * 4, cc * 4, 3, padding=1), nn.SiLU(),
+                                                nn.Conv2d(cc * 4, cc, 3, padding=1))
+        self.local_temporal_encoder = _FrameTransformer(heads=2, dim=cc, dim_head=cc, mlp_dim=cc,
+                                                        depth=adapter_transformer_layers)
+        self.local_image_embedding = nn.Sequential(nn.Conv2d(4, cc * 8, 3, padding=1), nn.SiLU(),
+                                                   nn.AdaptiveAvgPool2d((32, 32)),
+                                                   nn.Conv2d(cc * 8, cc * 16, 3, stride=2, padding=1), nn.SiLU(),
+                                                   nn.Conv2d(cc * 16, 1024, 3, stride=2, padding=1))
+        self._stem_cache = None
+
+    def invalidate(self):
+        super().invalidate()
+        self._stem_cache = None
+
+    # -- condition stems (prompt constants) ----------------------------------------------------------
+    @torch.no_grad()
+    def condition_stems(self, local_image, image, B, F, H, W):
+        """-> (concat [B, concat_dim, F, H, W] fp32, extra context [B, 64 (+ num_tokens), context_dim] fp32)."""
+        key = (local_image.data_ptr(), local_image._version, tuple(local_image.shape),
+               None if image is None else (image.data_ptr(), image._version), B, F, H, W)
+        if self._stem_cache is not None and self._stem_cache[0] == key:
+            return self._stem_cache[1]
+        li = local_image.float()
+        li = li[:, :, :1] if li.dim() == 5 else li.unsqueeze(2)                    # [B, 4, 1, H, W]
+        # frame 0 = the image latent, frames 1.. = their relative time (t+1)/(F-1) in every channel (:282-288)
+        frames = [li]
+        for tpos in range(F - 1):
+            frames.append(torch.full_like(li, (tpos + 1) / (F - 1)))
+        xi = torch.cat(frames, 2).permute(0, 2, 1, 3, 4).reshape(B * F, li.shape[1], H, W)
+        xi = self.local_image_concat(xi)                                           # [(B F), cc, H, W]
+        cc = xi.shape[1]
+        seq = xi.view(B, F, cc, H, W).permute(0, 3, 4, 1, 2).reshape(B * H * W, F, cc)
+        seq = self.local_temporal_encoder(seq)
+        concat = seq.view(B, H, W, F, cc).permute(0, 4, 3, 1, 2)
+        concat = (concat + concat).contiguous()          # the reference adds the map twice (:294-295), kept
+        lc = self.local_image_embedding(li[:, :, 0])                               # [B, 1024, 8, 8]
+        extra = lc.flatten(2).transpose(1, 2)                                      # [B, 64, 1024]
+        if image is not None:
+            ic = self.context_embedding(image.float()).view(-1, self.num_tokens, self.context_dim)
+            extra = torch.cat([extra, ic], 1)
+        out = (concat, extra.contiguous())
+        self._stem_cache = (key, out)
+        return out
+
+    @torch.no_grad()
+    def forward(self, x, t, y=None, image=None, local_image=None, masked=None, fps=None, video_mask=None,
+                focus_present_mask=None, prob_focus_present=0., mask_last_frame_num=0, **kwargs):
+        if local_image is None or fps is None:
+            raise ValueError("UNetSD_I2VGen.forward needs local_image and fps (unet_i2vgen.py:262-265,298)")
+        B, C, F, H, W = x.shape
+        concat, extra = self.condition_stems(local_image, image, B, F, H, W)
+        ctx = y if y is not None else self.zero_y.repeat(B, 1, 1)[:, :1, :]
+        ctx = torch.cat([ctx.float(), extra.to(ctx.device)], 1)                    # text | local | global tokens
+        return self._trunk(torch.cat([x.float(), concat], 1), t, ctx, fps)
+
+    def forward_units(self, x, t, kwargs_list):
+        """CFG pair as one batch (see UNetSD_T2VBase.forward_units); image conditions are stacked as well."""
+        G = len(kwargs_list)
+        if any(kw.get("y") is None for kw in kwargs_list):
+            return tuple(self.forward(x, t, **kw) for kw in kwargs_list)
+
+        def cat(name):
+            vals = [kw.get(name) for kw in kwargs_list]
+            return None if any(v is None for v in vals) else torch.cat([v.reshape((x.shape[0],) + tuple(v.shape[1:]))
+                                                                        if v.dim() > 1 else v.reshape(-1) for v in vals], 0)
+
+        out = self.forward(x.repeat(G, 1, 1, 1, 1), t.repeat(G), y=cat("y"), image=cat("image"),
+                           local_image=cat("local_image"), fps=cat("fps"))
+        return tuple(out.chunk(G, 0))
