@@ -288,6 +288,14 @@ int vgen_lowfreq_filter(const float* x, int64_t nimg, int32_t H, int32_t W, int3
 /* x[:, c0:c1] *= s in place on rows [M, C] fp32 (unet_sr600.py:278,284: backbone half-channel boost). */
 int vgen_scale_channels(float* x, int64_t M, int32_t C, int32_t c0, int32_t c1, float s, void* stream);
 
+/* Decoded frames to displayable bytes — the step right after AutoencoderKL.decode in every engine:
+ * utils/video_op.py:181-188 (`gen_video.mul_(std).add_(mean)`, `clamp_(0, 1)`, `* 255.0`, rearrange
+ * 'b c f h w -> b f h w c', `.astype('uint8')`).  x: decoder output rows [rows = n*H*W, C] fp32 (row stride
+ * ldx) — rows are already in (frame, y, x, channel) order, so out [rows*C] uint8 IS the [n, H, W, C] byte
+ * image; mean / stdv: C device floats.  Bit-exact with the reference arithmetic (fp32, truncation). */
+int vgen_frames_u8(const float* x, int64_t rows, int32_t C, int64_t ldx, const float* mean,
+                   const float* stdv, void* out, void* stream);
+
 size_t vgen_cfg_stats_ws_bytes(int64_t B);
 int vgen_cfg_stats(const float* y, const float* u, float guide, int32_t use_guide, int64_t B,
                    int64_t per_b, float* out, void* ws, size_t ws_bytes, void* stream);

@@ -213,6 +213,12 @@ class EmuBackend:
                 acc += (X[:, None, None, :] * torch.exp(1j * ph)[None, :, :, None]).real
         return (v + (scale - 1.0) / (H * W) * acc).float().view(nimg * H * W, C)
 
+    def frames_u8(self, x, mean, std):
+        v = x * std[None, :]
+        v = v + mean[None, :]
+        v = v.clamp(0.0, 1.0) * 255.0
+        return v.to(torch.int32).to(torch.uint8)          # truncation, like numpy astype('uint8') on [0, 255]
+
     def scale_channels(self, x, c0, c1, s):
         from vgen_amd.ops import drop_colstats
         x[:, c0:c1] *= s

@@ -89,3 +89,17 @@ def test_pointwise_and_gaussian(hip_backend):
 def test_cfg_ddim_step_bit_exact(hip_backend, mean_type, eta):
     res = kc.case_cfg_ddim(hip_backend, DEV, mean_type, eta)
     assert res["xt_1"]["bit_exact"] and res["x0"]["bit_exact"], res
+
+
+def test_frames_u8_bit_exact(hip_backend):
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(4001, 3, generator=gen) * 1.3
+    x[:7, 0] = torch.tensor([1.0, -1.0, 0.0, 0.999999, -0.9999999, 1.0000001, 0.00392])
+    mean = torch.tensor([0.5, 0.4, 0.6])
+    std = torch.tensor([0.5, 0.55, 0.45])
+    ref = kc.EMU.frames_u8(x, mean, std)
+    out = hip_backend.frames_u8(x.to(DEV), mean.to(DEV), std.to(DEV))
+    assert out.dtype == torch.uint8 and torch.equal(out.cpu(), ref)
+    xp = torch.randn(100, 8, generator=gen)                    # strided rows (ldx > C)
+    out = hip_backend.frames_u8(xp.to(DEV)[:, :3], mean.to(DEV), std.to(DEV))
+    assert torch.equal(out.cpu(), kc.EMU.frames_u8(xp[:, :3], mean, std))

@@ -182,3 +182,26 @@ def test_i2vgen_oracle_and_host_logic_vs_reference_golden(emu_backend):
     kw2 = dict(kw, y=torch.roll(g["y"], 1, 1))
     a, b = m.forward_units(g["x"], g["t"], [kw, kw2])
     assert rel_l2(a, m(g["x"], g["t"], **kw)) < 1e-5 and rel_l2(b, m(g["x"], g["t"], **kw2)) < 1e-5
+
+
+# ---- f3: decode epilogue to displayable bytes + engine glue a21 ---------------------------------------------
+def test_decode_to_uint8_and_decode_video_match_the_engine_post_processing(emu_backend):
+    from vgen_amd.vae import AutoencoderKL
+    g = gold("vae_tiny.pt")
+    v = AutoencoderKL(ddconfig=g["ddconfig"], embed_dim=4, compute_dtype="fp16").eval()
+    v.load_state_dict(torch_ref.synth_state_dict(g["shapes"], seed=g["seed"]), strict=True)
+    z = g["z"] * 3.0                                         # push some pixels past the clamp
+    dec = v.decode(z)
+    # utils/video_op.py:181-188 on the decoded frames, restated: mul_(std).add_(mean).clamp_(0,1)*255 -> uint8
+    ref = ((dec * 0.5 + 0.5).clamp(0, 1) * 255.0).permute(0, 2, 3, 1).contiguous().numpy().astype("uint8")
+    u8 = v.decode_to_uint8(z)
+    assert u8.dtype == torch.uint8 and tuple(u8.shape) == ref.shape
+    assert (u8.numpy() == ref).all()
+    assert 0 in u8 and 255 in u8
+    # a21: latents [B, 4, F, h, w] -> per-video frames, chunked by decoder_bs
+    lat = (z * 0.18215).view(1, 2, 4, *z.shape[2:]).permute(0, 2, 1, 3, 4).contiguous()
+    vid = v.decode_video(lat, scale_factor=0.18215, decoder_bs=1)
+    assert tuple(vid.shape) == (1, 2) + ref.shape[1:]
+    assert (vid[0].numpy().astype(int) - ref.astype(int)).__abs__().max() <= 1     # 1/s * (s * z) is not exactly z
+    f32 = v.decode_video(lat, scale_factor=0.18215, decoder_bs=2, to_uint8=False)
+    assert tuple(f32.shape) == (1, 3, 2) + tuple(dec.shape[2:]) and rel_l2(f32[0].permute(1, 0, 2, 3), dec) < 1e-3

@@ -484,7 +484,36 @@ __global__ __launch_bounds__(256) void scale_channels_kernel(float* __restrict__
   x[m * C + c] *= sc;
 }
 
+// decoded frames -> displayable bytes.  Same fp32 operation order as the reference's
+// gen_video.mul_(std).add_(mean).clamp_(0, 1) * 255 -> astype(uint8): no contraction, truncation.
+__global__ __launch_bounds__(256) void frames_u8_kernel(const float* __restrict__ x, int64_t rows, int C,
+                                                        int64_t ldx, const float* __restrict__ mean,
+                                                        const float* __restrict__ stdv,
+                                                        uint8_t* __restrict__ out) {
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * C) return;
+  const int64_t r = i / C;
+  const int c = (int)(i - r * C);
+  float v = x[r * ldx + c] * stdv[c];
+  v = v + mean[c];
+  v = fminf(fmaxf(v, 0.0f), 1.0f);
+  v = v * 255.0f;
+  out[i] = (uint8_t)(int)v;
+}
+
 }  // namespace
+
+extern "C" int vgen_frames_u8(const float* x, int64_t rows, int32_t C, int64_t ldx, const float* mean,
+                              const float* stdv, void* out, void* stream) {
+  VGEN_REQUIRE(x && mean && stdv && out && rows >= 0 && C > 0 && ldx >= C, "frames_u8: args");
+  const int64_t n = rows * C;
+  if (n == 0) return 0;
+  VGEN_REQUIRE((n + 255) / 256 < (1LL << 31), "frames_u8: too large");
+  hipLaunchKernelGGL(frames_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     rows, C, ldx, mean, stdv, (uint8_t*)out);
+  return vgen_check_launch("frames_u8");
+}
 
 extern "C" int vgen_lowfreq_filter(const float* x, int64_t nimg, int32_t H, int32_t W, int32_t C, float scale,
                                    float* y, float* ws, size_t ws_bytes, void* stream) {

@@ -81,6 +81,7 @@ SYMBOLS = {
     "vgen_gaussian_sample": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _f32, _vp, _vp]),
     "vgen_lowfreq_filter": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _sz, _vp]),
     "vgen_scale_channels": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _f32, _vp]),
+    "vgen_frames_u8": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _vp, _vp, _vp]),
     "vgen_cfg_stats_ws_bytes": (_sz, [_i64]),
     "vgen_cfg_stats": (C.c_int, [_vp, _vp, _f32, _i32, _i64, _i64, _vp, _vp, _sz, _vp]),
     "vgen_gauss_x0": (C.c_int, [_vp, _vp, _vp, _f32, _vp, _i32, _i64, _i64, _vp, _vp, _vp]),

@@ -324,6 +324,16 @@ class HipBackend:
         drop_colstats(x)           # modified in place: the producer's statistics no longer describe it
         return x
 
+    def frames_u8(self, x, mean, std):
+        """rows [n*H*W, C] fp32 -> uint8 [n*H*W, C] = clamp(x*std + mean, 0, 1) * 255, truncated."""
+        x = _mat(x, "x")
+        assert x.dtype == torch.float32 and mean.dtype == torch.float32 and std.dtype == torch.float32
+        out = torch.empty((x.shape[0], x.shape[1]), dtype=torch.uint8, device=x.device)
+        rc = self.lib.vgen_frames_u8(_ptr(x), x.shape[0], x.shape[1], x.stride(0), _ptr(mean), _ptr(std), _ptr(out),
+                                     self._stream(x))
+        _lib.check(rc, "vgen_frames_u8")
+        return out
+
     def gauss_denoise(self, xt, y, u, guide, rescale, coef, pred_type, want_eps):
         """CFG (+guide_rescale) + x0 (+eps) of GaussianDiffusion.denoise; all fp32 contiguous."""
         for t in (xt, y, u, coef):

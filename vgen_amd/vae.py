@@ -296,6 +296,45 @@ class AutoencoderKL(nn.Module):
     # -- public API ----------------------------------------------------------------------------------
     @torch.no_grad()
     def decode(self, z, **kwargs):
+        o, n, H, W = self._decode_rows(z)
+        be = ops.backend()
+        oc = o.shape[1]
+        out = torch.empty((n, oc, H, W), dtype=torch.float32, device=z.device)
+        be.pointwise_small(o, n, 1, oc, H, W, (H * W * oc, 0, 1, W * oc, oc), self._packed["eye"][oc], None, oc,
+                           out, (oc * H * W, 0, H * W, W, 1))
+        return out
+
+    @torch.no_grad()
+    def decode_to_uint8(self, z, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5)):
+        """decode + the engines' post-processing (utils/video_op.py:181-188) in one pass: the decoder's rows
+        are already (frame, y, x, channel)-ordered, so the byte image [n, H, W, 3] is written straight from
+        them — no NCHW tensor, no fp32 D2H of 22 MB per video."""
+        o, n, H, W = self._decode_rows(z)
+        key = (tuple(mean), tuple(std), o.device)
+        if getattr(self, "_u8_consts", (None,))[0] != key:
+            self._u8_consts = (key, torch.tensor(mean, dtype=torch.float32, device=o.device),
+                               torch.tensor(std, dtype=torch.float32, device=o.device))
+        return ops.backend().frames_u8(o, self._u8_consts[1], self._u8_consts[2]).view(n, H, W, o.shape[1])
+
+    @torch.no_grad()
+    def decode_video(self, latents, scale_factor=0.18215, decoder_bs=2, to_uint8=True, **u8):
+        """Engine glue a21 (inference_text2video_entrance.py:208-217): latents [B, 4, F, h, w] -> frames, i.e.
+        `1/scale_factor * x`, '(b f) c h w' chunks of decoder_bs through decode, back to per-video order.
+        Returns uint8 [B, F, H, W, 3] (to_uint8) or fp32 [B, 3, F, H, W] like the reference."""
+        B, C, F, h, w = latents.shape
+        z = (latents.float() * (1.0 / scale_factor)).permute(0, 2, 1, 3, 4).reshape(B * F, C, h, w)
+        outs = []
+        for i in range(0, B * F, decoder_bs):
+            zc = z[i:i + decoder_bs]
+            outs.append(self.decode_to_uint8(zc, **u8) if to_uint8 else self.decode(zc))
+        o = torch.cat(outs, 0)
+        if to_uint8:
+            return o.view(B, F, *o.shape[1:])
+        return o.view(B, F, *o.shape[1:]).permute(0, 2, 1, 3, 4)
+
+    @torch.no_grad()
+    def _decode_rows(self, z):
+        """-> (decoder output rows [n*H*W, out_ch] fp32, n, H, W)"""
         be, dt = ops.backend(), self.compute_dtype
         if self._packed is None:
             self.pack()
@@ -320,11 +359,7 @@ class AutoencoderKL(nn.Module):
                 h, H, W = self._conv(a, P[lvl.upsample._pname], n, H, W, h.shape[1], ups=1)
         a, _ = be.groupnorm(h, None, n, H * W, 32, 1e-6, *P["decoder.norm_out"], True, False, dt)
         o, _, _ = self._conv(a, P["decoder.conv_out"], n, H, W, h.shape[1])
-        oc = o.shape[1]
-        out = torch.empty((n, oc, H, W), dtype=torch.float32, device=z.device)
-        be.pointwise_small(o, n, 1, oc, H, W, (H * W * oc, 0, 1, W * oc, oc), P["eye"][oc], None, oc,
-                           out, (oc * H * W, 0, H * W, W, 1))
-        return out
+        return o, n, H, W
 
     @torch.no_grad()
     def _encode_rows(self, x):
