@@ -95,10 +95,14 @@ __device__ __forceinline__ float wave_max(float v) {
 
 // raw v_exp_f32 (2^x): -inf -> 0, no denormal fix-up sequence (4 extra VALU ops per call in exp2f)
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + expf(-x)); }
+// SiLU on the raw transcendentals: v_exp_f32 + v_rcp_f32 (1 ulp each) and 3 VALU ops.  The libm form
+// x / (1 + expf(-x)) expands to ~22 VALU instructions + the same two transcendentals (range fix-ups of expf,
+// IEEE division sequence): the GroupNorm apply pass was VALU-bound on it, not HBM-bound.
+// x -> -inf: exp2 = +inf, rcp = 0, result -0;  x -> +inf: exp2 = 0, rcp(1) = 1, result x.
+__device__ __forceinline__ float silu_f(float x) {
+  return x * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896340736f * x));
+}
 
-// erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the 16-bit output rounding):
-// ~12 instructions instead of libm erff's ~40 — the GEGLU epilogue evaluates 32 per lane per tile.
 // erf for the exact-GELU gate of GEGLU (util.py:707-714, F.gelu default): odd minimax polynomial
 // x * P(x^2), degree 8 in x^2, on |x| <= 3 (clamped: 1 - erf(3) = 2.2e-5).  Max abs error 2.2e-5 — GELU
 // relative L2 error 8.5e-6 over N(0, 1.5) gates, two orders below the 16-bit rounding of the output it
