@@ -33,7 +33,7 @@ __device__ __forceinline__ int64_t seq_off(int64_t bi, int64_t inner, int64_t bo
 
 // =========================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void flash_kernel(const vgen_attn_args p, int qtiles) {
+__global__ __launch_bounds__(256, 2) void flash_kernel(const vgen_attn_args p, int qtiles) {
   constexpr int BQ = 128, BKV = 64;
   constexpr int VS = 72;  // V^T row stride in elements (64 keys + 8 pad) -> 144 B
   // double-buffered K / V^T tiles: the global loads of tile t+1 are issued before the MFMAs of
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void flash_kernel(const vgen_attn_args p, int 
 
 // =========================================================================================
 template <typename T>
-__global__ __launch_bounds__(256) void temporal_kernel(const vgen_attn_args p, int64_t npairs) {
+__global__ __launch_bounds__(256, 2) void temporal_kernel(const vgen_attn_args p, int64_t npairs) {
   constexpr int VS = 72;
   __shared__ __attribute__((aligned(16))) uint16_t sV[4][16 * VS];  // per wave: [key][64 d + pad]
 
