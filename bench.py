@@ -178,7 +178,9 @@ def main():
         tt = torch.tensor([dt_s], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt_s = float(tt.item())
-    finite = bool(torch.isfinite(state["xt"] if not use_graph else static_in).all())
+    xt_end = state["xt"] if not use_graph else static_in
+    finite = bool(torch.isfinite(xt_end).all())
+    xt_absmax = float(xt_end.float().abs().nan_to_num(nan=float("inf")).max())
 
     steps_per_s = P * args.steps / dt_s
     res = {
@@ -191,7 +193,7 @@ def main():
                    "prompts_in_flight": P, "units_per_step": 2 * P,
                    "parallelism": "single GPU" if world == 1 else f"unit partition over {world} ranks, 1 all-gather/step",
                    "hipgraph": "whole step" if use_graph else ("local forward" if step_model is not model else False)},
-        "finite": finite,
+        "finite": finite, "latent_absmax_after_timed_steps": xt_absmax,
         "model_tflops_per_s": round(2 * UNET_FWD_TFLOP * steps_per_s, 2),
     }
 

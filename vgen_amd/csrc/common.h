@@ -104,7 +104,9 @@ __device__ __forceinline__ float silu_f(float x) {
 }
 
 // erf for the exact-GELU gate of GEGLU (util.py:707-714, F.gelu default): odd minimax polynomial
-// x * P(x^2), degree 8 in x^2, on |x| <= 3 (clamped: 1 - erf(3) = 2.2e-5).  Max abs error 2.2e-5 — GELU
+// x * P(x^2), degree 8 in x^2, on |x| < 3 and exactly +-1 beyond (1 - erf(3) = 2.2e-5; the exact
+// saturation matters: with a clamped polynomial gelu(g) -> 1.1e-5 * g instead of 0 for very negative
+// gates, an error that grows with |g|).  Max abs error 2.2e-5 — GELU
 // relative L2 error 8.5e-6 over N(0, 1.5) gates, two orders below the 16-bit rounding of the output it
 // feeds.  No transcendental: the A&S 7.1.26 form used before (v_rcp + v_exp per element, quarter rate)
 // made the gate 21 % of the 57344 x 2560 x 320 GEGLU GEMM (201 -> 159 us without it).
@@ -118,8 +120,8 @@ __device__ __forceinline__ float silu_f(float x) {
 #define VGEN_ERF_C7 -1.944825013e-06f
 #define VGEN_ERF_C8 4.074217005e-08f
 
-__device__ __forceinline__ float erf_poly(float x) {
-  x = fminf(fmaxf(x, -3.0f), 3.0f);
+__device__ __forceinline__ float erf_poly(float x0) {
+  const float x = fminf(fmaxf(x0, -3.0f), 3.0f);
   const float u = x * x;
   float p = VGEN_ERF_C8;
   p = p * u + VGEN_ERF_C7;
@@ -130,7 +132,7 @@ __device__ __forceinline__ float erf_poly(float x) {
   p = p * u + VGEN_ERF_C2;
   p = p * u + VGEN_ERF_C1;
   p = p * u + VGEN_ERF_C0;
-  return p * x;
+  return fabsf(x0) < 3.0f ? p * x : copysignf(1.0f, x0);
 }
 __device__ __forceinline__ float gelu_erf_f(float x) {
   const float h = 0.5f * x;
@@ -140,9 +142,10 @@ __device__ __forceinline__ float gelu_erf_f(float x) {
 // v_pk_fma_f32 / v_pk_mul_f32 (2 floats per VALU op).  Same operation order as gelu_erf_f (the split-K
 // reducer's scalar path).
 __device__ __forceinline__ f32x4 geglu4(f32x4 val, f32x4 g) {
-  f32x4 x = g * 0.70710678118654752440f;
+  const f32x4 x0 = g * 0.70710678118654752440f;
+  f32x4 x;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) x[i] = fminf(fmaxf(x[i], -3.0f), 3.0f);
+  for (int i = 0; i < 4; ++i) x[i] = fminf(fmaxf(x0[i], -3.0f), 3.0f);
   const f32x4 u = x * x;
   f32x4 p = u * VGEN_ERF_C8 + VGEN_ERF_C7;
   p = p * u + VGEN_ERF_C6;
@@ -152,7 +155,9 @@ __device__ __forceinline__ f32x4 geglu4(f32x4 val, f32x4 g) {
   p = p * u + VGEN_ERF_C2;
   p = p * u + VGEN_ERF_C1;
   p = p * u + VGEN_ERF_C0;
-  const f32x4 e = p * x;
+  f32x4 e = p * x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) e[i] = fabsf(x0[i]) < 3.0f ? e[i] : copysignf(1.0f, x0[i]);
   const f32x4 h = g * 0.5f;
   return val * (h + h * e);
 }
