@@ -88,6 +88,28 @@ def make_i2vgen(R):
     print("unet_i2vgen_tiny", tuple(out.shape), float(out.std()))
 
 
+LCM_TINY = dict(in_dim=4, dim=64, y_dim=1024, context_dim=1024, concat_dim=8, out_dim=4, dim_mult=[1, 2, 4],
+                num_heads=2, head_dim=64, num_res_blocks=1, attn_scales=[1.0, 0.5, 0.25], dropout=0.1,
+                temporal_attention=True, temporal_attn_times=1, use_checkpoint=False, use_fps_condition=False,
+                use_sim_mask=False, num_tokens=4, training=False)
+
+
+def make_videolcm(R):
+    """tiny UNetSD_VideoLCM, text-only composition (configs/videolcm_t2v_infer.yaml:67), float timesteps."""
+    import types
+    cfg = types.SimpleNamespace(video_compositions=["text"], resolution=[64, 128])
+    ref = R["MODEL"].build(dict(type="UNetSD_VideoLCM", config=cfg, **LCM_TINY)).eval()
+    shapes = torch_ref.shapes_of(ref)
+    ref.load_state_dict(torch_ref.synth_state_dict(shapes, seed=5), strict=True)
+    x, y = _inputs(13, 2, 4, 16, 8)
+    t = torch.tensor([759.0, 259.0])                      # the LCM engine passes float timesteps
+    with torch.no_grad():
+        out = ref(x, t, y=y)
+    torch.save(dict(cfg=LCM_TINY, seed=5, shapes=shapes, x=x, t=t, y=y, out=out),
+               os.path.join(GOLD, "unet_videolcm_tiny.pt"))
+    print("unet_videolcm_tiny", tuple(out.shape), float(out.std()))
+
+
 @torch.no_grad()
 def main():
     ap = argparse.ArgumentParser()
@@ -98,6 +120,9 @@ def main():
     R = ref_import.load()
     if args.only == "i2vgen":
         make_i2vgen(R)
+        return
+    if args.only == "videolcm":
+        make_videolcm(R)
         return
     torch.manual_seed(0)
 
@@ -181,6 +206,7 @@ def main():
                os.path.join(GOLD, "unet_sr600_tiny.pt"))
     print("unet_sr600_tiny", tuple(osr.shape), float(osr.std()))
     make_i2vgen(R)
+    make_videolcm(R)
 
     # ---- tiny VAE ------------------------------------------------------------------------------
     vae = R["AUTO_ENCODER"].build(dict(type="AutoencoderKL", ddconfig=VAE_TINY, embed_dim=4)).eval()

@@ -233,6 +233,13 @@ def unet_i2vgen_forward(sd, x, t, y, image, local_image, fps, dim, num_tokens=4,
     return unet_forward(sd, torch.cat([x, concat], 1), t, torch.cat([y, extra], 1), dim, fps=fps)
 
 
+def unet_videolcm_text_forward(sd, x, t, y, dim, concat_dim):
+    """UNetSD_VideoLCM.forward with video_compositions == ['text'] (unet_videolcm.py:598, 702-705, 709-784):
+    zero concat buffer, identity pre_image, text-only context, then the shared trunk."""
+    b, c, f, h, w = x.shape
+    return unet_forward(sd, torch.cat([x, x.new_zeros(b, concat_dim, f, h, w)], 1), t, y, dim)
+
+
 def unet_forward(sd, x, t, y, dim, down_padding=1, up_crop=0, freeu=None, fps=None):
     """UNetSD_T2VBase.forward / _forward_single, unet/unet_t2v.py:210-348 (y given; `fps` adds the
     fps embedding, :244-245 / unet_i2vgen.py:298).  The block structure is recovered from the state_dict keys."""

@@ -205,3 +205,24 @@ def test_decode_to_uint8_and_decode_video_match_the_engine_post_processing(emu_b
     assert (vid[0].numpy().astype(int) - ref.astype(int)).__abs__().max() <= 1     # 1/s * (s * z) is not exactly z
     f32 = v.decode_video(lat, scale_factor=0.18215, decoder_bs=2, to_uint8=False)
     assert tuple(f32.shape) == (1, 3, 2) + tuple(dec.shape[2:]) and rel_l2(f32[0].permute(1, 0, 2, 3), dec) < 1e-3
+
+
+# ---- UNetSD_VideoLCM, text-only composition ------------------------------------------------
+def test_videolcm_text_oracle_and_host_logic_vs_reference_golden(emu_backend):
+    import types
+    from vgen_amd.unet_videolcm import UNetSD_VideoLCM
+    g = gold("unet_videolcm_tiny.pt")
+    sd = torch_ref.synth_state_dict(g["shapes"], seed=g["seed"])
+    ref = torch_ref.unet_videolcm_text_forward(sd, g["x"], g["t"], g["y"], g["cfg"]["dim"], g["cfg"]["concat_dim"])
+    assert rel_l2(ref, g["out"]) < 2e-5
+    cfg = types.SimpleNamespace(video_compositions=["text"], resolution=[64, 128])
+    m = UNetSD_VideoLCM(config=cfg, **g["cfg"], compute_dtype="fp16").eval()
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v) for k, v in g["shapes"].items()}
+    m.load_state_dict(sd, strict=True)
+    out = m(g["x"], g["t"], y=g["y"])                       # float timesteps, like the LCM engine
+    assert out.shape == g["out"].shape and rel_l2(out, g["out"]) < 3e-3
+    with pytest.raises(NotImplementedError):
+        m(g["x"], g["t"], y=g["y"], depth=torch.zeros(1))
+    with pytest.raises(NotImplementedError):
+        UNetSD_VideoLCM(config=types.SimpleNamespace(video_compositions=["text", "depthmap"], resolution=[64, 128]),
+                        **g["cfg"])
