@@ -562,3 +562,53 @@ def gauss_ddim_reverse_loop(tabs, x0, model, model_kwargs, prediction_type, ddim
         a_s = tabs["alphas"][s].view(shape)
         xt = a_s * px0 + torch.sqrt(1 - a_s ** 2) * eps
     return xt
+
+
+# ------------------------------------------------------------------------------------------
+# LCM multistep consistency sampler — PARITY UNPINNED: `diffusers.LCMScheduler` is not under
+# /root/reference and not version-pinned; restated from the published algorithm with the engine's ctor
+# arguments (inference_videolcm_entrance.py:171) and loop (:228-257).
+# ------------------------------------------------------------------------------------------
+
+
+def lcm_alphas_cumprod(T=1000, beta_start=0.00085, beta_end=0.012, zero_snr=True):
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, T, dtype=torch.float32) ** 2
+    if zero_snr:
+        a = (1.0 - betas).cumprod(0).sqrt()
+        a0, aT = a[0].clone(), a[-1].clone()
+        a = (a - aT) * (a0 / (a0 - aT))
+        ab = a ** 2
+        betas = 1.0 - torch.cat([ab[:1], ab[1:] / ab[:-1]])
+    return torch.cumprod(1.0 - betas, 0)
+
+
+def lcm_timesteps(n, T=1000, original_steps=50):
+    import numpy as np
+    k = T // original_steps
+    origin = (np.arange(1, original_steps + 1) * k - 1)[::-1].copy()
+    idx = np.floor(np.linspace(0, len(origin), num=n, endpoint=False)).astype(np.int64)
+    return [int(v) for v in origin[idx]]
+
+
+def lcm_sample_loop(ac, timesteps, noise, model, model_kwargs, guidance_scale, step_noise, prediction_type="v_prediction",
+                    timestep_scaling=10.0):
+    x = noise.clone()
+    for i, t in enumerate(timesteps):
+        tt = torch.full((x.shape[0],), float(t))
+        v = model(x, tt, **model_kwargs[0])
+        if guidance_scale is not None:
+            u = model(x, tt, **model_kwargs[1])
+            v = u + torch.tensor(guidance_scale, dtype=torch.float32) * (v - u)
+        a_t = ac[t]
+        prev_t = timesteps[i + 1] if i + 1 < len(timesteps) else t
+        a_prev = ac[prev_t]
+        s = t * timestep_scaling
+        c_skip = 0.25 / (s ** 2 + 0.25)
+        c_out = s / (s ** 2 + 0.25) ** 0.5
+        if prediction_type == "v_prediction":
+            x0 = a_t.sqrt() * x - (1 - a_t).sqrt() * v
+        else:
+            x0 = (x - (1 - a_t).sqrt() * v) / a_t.sqrt()
+        den = c_out * x0 + c_skip * x
+        x = a_prev.sqrt() * den + (1 - a_prev).sqrt() * step_noise[i] if i != len(timesteps) - 1 else den
+    return x
