@@ -110,6 +110,23 @@ def make_videolcm(R):
     print("unet_videolcm_tiny", tuple(out.shape), float(out.std()))
 
 
+def make_tft2v(R):
+    """tiny UNetSD_TFT2V with the compositions of configs/tft2v_t2v_infer.yaml:65 (['text', 'image'])."""
+    import types
+    cfg = types.SimpleNamespace(video_compositions=["text", "image"], resolution=[64, 128])
+    ref = R["MODEL"].build(dict(type="UNetSD_TFT2V", config=cfg, **LCM_TINY)).eval()
+    shapes = torch_ref.shapes_of(ref)
+    ref.load_state_dict(torch_ref.synth_state_dict(shapes, seed=6), strict=True)
+    x, y = _inputs(17, 2, 4, 16, 8)
+    image = torch.randn(2, 1, 1024, generator=torch.Generator("cpu").manual_seed(18))
+    t = torch.tensor([981, 401])
+    with torch.no_grad():
+        out = ref(x, t, y=y, image=image)
+    torch.save(dict(cfg=LCM_TINY, seed=6, shapes=shapes, x=x, t=t, y=y, image=image, out=out),
+               os.path.join(GOLD, "unet_tft2v_tiny.pt"))
+    print("unet_tft2v_tiny", tuple(out.shape), float(out.std()))
+
+
 @torch.no_grad()
 def main():
     ap = argparse.ArgumentParser()
@@ -123,6 +140,9 @@ def main():
         return
     if args.only == "videolcm":
         make_videolcm(R)
+        return
+    if args.only == "tft2v":
+        make_tft2v(R)
         return
     torch.manual_seed(0)
 
@@ -207,6 +227,7 @@ def main():
     print("unet_sr600_tiny", tuple(osr.shape), float(osr.std()))
     make_i2vgen(R)
     make_videolcm(R)
+    make_tft2v(R)
 
     # ---- tiny VAE ------------------------------------------------------------------------------
     vae = R["AUTO_ENCODER"].build(dict(type="AutoencoderKL", ddconfig=VAE_TINY, embed_dim=4)).eval()

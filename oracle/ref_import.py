@@ -82,6 +82,7 @@ def load():
     mods = {}
     for n in ("tools.modules.unet.util", "tools.modules.unet.unet_t2v", "tools.modules.unet.unet_sr600",
               "tools.modules.unet.unet_i2vgen", "tools.modules.unet.unet_videolcm",
+              "tools.modules.unet.unet_tf2tv",
               "tools.modules.autoencoder",
               "tools.modules.diffusions.schedules", "tools.modules.diffusions.losses",
               "tools.modules.diffusions.diffusion_ddim", "tools.modules.diffusions.diffusion_gauss"):

@@ -233,11 +233,17 @@ def unet_i2vgen_forward(sd, x, t, y, image, local_image, fps, dim, num_tokens=4,
     return unet_forward(sd, torch.cat([x, concat], 1), t, torch.cat([y, extra], 1), dim, fps=fps)
 
 
-def unet_videolcm_text_forward(sd, x, t, y, dim, concat_dim):
-    """UNetSD_VideoLCM.forward with video_compositions == ['text'] (unet_videolcm.py:598, 702-705, 709-784):
-    zero concat buffer, identity pre_image, text-only context, then the shared trunk."""
+def unet_videolcm_text_forward(sd, x, t, y, dim, concat_dim, image=None, num_tokens=4, context_dim=1024):
+    """UNetSD_VideoLCM / UNetSD_TFT2V.forward with video_compositions within ['text', 'image']
+    (unet_videolcm.py:598, 702-705, 709-784; unet_tf2tv.py likewise): zero concat buffer, identity pre_image,
+    context = text tokens (+ num_tokens global-image tokens from pre_image_condition, :743-745), shared trunk."""
     b, c, f, h, w = x.shape
-    return unet_forward(sd, torch.cat([x, x.new_zeros(b, concat_dim, f, h, w)], 1), t, y, dim)
+    ctx = y
+    if image is not None:
+        ic = F.linear(F.silu(F.linear(image, sd["pre_image_condition.0.weight"], sd["pre_image_condition.0.bias"])),
+                      sd["pre_image_condition.2.weight"], sd["pre_image_condition.2.bias"])
+        ctx = torch.cat([ctx, ic.reshape(-1, num_tokens, context_dim)], 1)
+    return unet_forward(sd, torch.cat([x, x.new_zeros(b, concat_dim, f, h, w)], 1), t, ctx, dim)
 
 
 def unet_forward(sd, x, t, y, dim, down_padding=1, up_crop=0, freeu=None, fps=None):

@@ -226,3 +226,23 @@ def test_videolcm_text_oracle_and_host_logic_vs_reference_golden(emu_backend):
     with pytest.raises(NotImplementedError):
         UNetSD_VideoLCM(config=types.SimpleNamespace(video_compositions=["text", "depthmap"], resolution=[64, 128]),
                         **g["cfg"])
+
+
+def test_tft2v_text_image_oracle_and_host_logic_vs_reference_golden(emu_backend):
+    import types
+    from vgen_amd.unet_videolcm import UNetSD_TFT2V
+    g = gold("unet_tft2v_tiny.pt")
+    sd = torch_ref.synth_state_dict(g["shapes"], seed=g["seed"])
+    ref = torch_ref.unet_videolcm_text_forward(sd, g["x"], g["t"], g["y"], g["cfg"]["dim"], g["cfg"]["concat_dim"],
+                                               image=g["image"])
+    assert rel_l2(ref, g["out"]) < 2e-5
+    cfg = types.SimpleNamespace(video_compositions=["text", "image"], resolution=[64, 128])
+    m = UNetSD_TFT2V(config=cfg, **g["cfg"], compute_dtype="fp16").eval()
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v) for k, v in g["shapes"].items()}
+    m.load_state_dict(sd, strict=True)
+    out = m(g["x"], g["t"], y=g["y"], image=g["image"])
+    assert out.shape == g["out"].shape and rel_l2(out, g["out"]) < 3e-3
+    kw = dict(y=g["y"], image=g["image"])
+    kw2 = dict(y=torch.roll(g["y"], 1, 1), image=g["image"] * 0.5)
+    a, b = m.forward_units(g["x"], g["t"], [kw, kw2])
+    assert rel_l2(a, out) < 1e-5 and rel_l2(b, m(g["x"], g["t"], **kw2)) < 1e-5

@@ -19,6 +19,7 @@ def test_native_registries_resolve_reference_names():
     assert regs["MODEL"].get("UNetSD_SR600").__module__ == "vgen_amd.unet"
     assert regs["MODEL"].get("UNetSD_I2VGen").__module__ == "vgen_amd.unet_i2vgen"
     assert regs["MODEL"].get("UNetSD_VideoLCM").__module__ == "vgen_amd.unet_videolcm"
+    assert regs["MODEL"].get("UNetSD_TFT2V").__module__ == "vgen_amd.unet_videolcm"
     assert regs["DIFFUSION"].get("DiffusionDDIMSR").__module__ == "vgen_amd.diffusion_gauss"
     assert regs["AUTO_ENCODER"].get("AutoencoderKL").__module__ == "vgen_amd.vae"
 
@@ -61,7 +62,7 @@ def test_extra_kwargs_and_unknown_cfg_keys_are_accepted():
 def test_install_overrides_the_reference_registries_in_place():
     from oracle import ref_import
     R = ref_import.load()
-    names = (("MODEL", "UNetSD_T2VBase"), ("MODEL", "UNetSD_SR600"), ("MODEL", "UNetSD_I2VGen"), ("MODEL", "UNetSD_VideoLCM"),
+    names = (("MODEL", "UNetSD_T2VBase"), ("MODEL", "UNetSD_SR600"), ("MODEL", "UNetSD_I2VGen"), ("MODEL", "UNetSD_VideoLCM"), ("MODEL", "UNetSD_TFT2V"),
              ("AUTO_ENCODER", "AutoencoderKL"), ("DIFFUSION", "DiffusionDDIM"), ("DIFFUSION", "DiffusionDDIMSR"))
     orig = {(k, n): R[k].get(n) for k, n in names}
     try:

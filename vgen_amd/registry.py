@@ -99,9 +99,9 @@ def _native_classes():
     from .diffusion_gauss import DiffusionDDIMSR
     from .unet import UNetSD_SR600, UNetSD_T2VBase
     from .unet_i2vgen import UNetSD_I2VGen
-    from .unet_videolcm import UNetSD_VideoLCM
+    from .unet_videolcm import UNetSD_TFT2V, UNetSD_VideoLCM
     from .vae import AutoencoderKL
-    return {"MODEL": [UNetSD_T2VBase, UNetSD_SR600, UNetSD_I2VGen, UNetSD_VideoLCM], "AUTO_ENCODER": [AutoencoderKL],
+    return {"MODEL": [UNetSD_T2VBase, UNetSD_SR600, UNetSD_I2VGen, UNetSD_VideoLCM, UNetSD_TFT2V], "AUTO_ENCODER": [AutoencoderKL],
             "DIFFUSION": [DiffusionDDIM, DiffusionDDIMSR]}
 
 
