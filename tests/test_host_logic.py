@@ -171,13 +171,15 @@ def test_i2vgen_oracle_and_host_logic_vs_reference_golden(emu_backend):
     kw = dict(y=g["y"], image=g["image"], local_image=g["local_image"], fps=g["fps"])
     out = m(g["x"], g["t"], **kw)
     assert out.shape == g["out"].shape and rel_l2(out, g["out"]) < 3e-3
-    # stems are prompt constants: cached per conditioning input, recomputed when it changes
-    c0 = m._stem_cache[1][0]
+    # stems are prompt constants: cached per conditioning tensor object, recomputed when it changes
+    stems = lambda li: m.condition_stems(li, g["image"], *g["x"].shape[:1], *g["x"].shape[2:])
+    c0 = stems(g["local_image"])[0]
     m(g["x"] * 0.5, g["t"], **kw)
-    assert m._stem_cache[1][0] is c0
-    li2 = g["local_image"] * 1.5
-    m(g["x"], g["t"], y=g["y"], image=g["image"], local_image=li2, fps=g["fps"])
-    assert m._stem_cache[1][0] is not c0
+    assert stems(g["local_image"])[0] is c0
+    li2 = g["local_image"] * 1.5                                  # another tensor: no aliasing by address
+    assert stems(li2)[0] is not c0 and rel_l2(stems(li2)[0], c0) > 1e-3
+    g["local_image"].mul_(1.0)                                    # in-place edit bumps _version -> recompute
+    assert stems(g["local_image"])[0] is not c0
     # CFG pair as one batch == two calls
     kw2 = dict(kw, y=torch.roll(g["y"], 1, 1))
     a, b = m.forward_units(g["x"], g["t"], [kw, kw2])

@@ -124,11 +124,16 @@ class UNetSD_I2VGen(UNetSD_T2VBase):
     # -- condition stems (prompt constants) ----------------------------------------------------------
     @torch.no_grad()
     def condition_stems(self, local_image, image, B, F, H, W):
-        """-> (concat [B, concat_dim, F, H, W] fp32, extra context [B, 64 (+ num_tokens), context_dim] fp32)."""
-        key = (local_image.data_ptr(), local_image._version, tuple(local_image.shape),
-               None if image is None else (image.data_ptr(), image._version), B, F, H, W)
-        if self._stem_cache is not None and self._stem_cache[0] == key:
-            return self._stem_cache[1]
+        """-> (concat [B, concat_dim, F, H, W] fp32, extra context [B, 64 (+ num_tokens), context_dim] fp32).
+        Cached per conditioning TENSOR OBJECT (the engine passes the same tensors on every denoise step); the
+        cache holds references to them, so a recycled allocation can never alias a stale entry, and their
+        `_version` counters catch in-place edits."""
+        key = (id(local_image), local_image._version, None if image is None else (id(image), image._version),
+               B, F, H, W)
+        cache = self._stem_cache if self._stem_cache is not None else {}
+        hit = cache.get(key)
+        if hit is not None and hit[0] is local_image and hit[1] is image:
+            return hit[2]
         li = local_image.float()
         li = li[:, :, :1] if li.dim() == 5 else li.unsqueeze(2)                    # [B, 4, 1, H, W]
         # frame 0 = the image latent, frames 1.. = their relative time (t+1)/(F-1) in every channel (:282-288)
@@ -148,8 +153,17 @@ class UNetSD_I2VGen(UNetSD_T2VBase):
             ic = self.context_embedding(image.float()).view(-1, self.num_tokens, self.context_dim)
             extra = torch.cat([extra, ic], 1)
         out = (concat, extra.contiguous())
-        self._stem_cache = (key, out)
+        if len(cache) >= 8:                              # a handful of prompts in flight; never grows unbounded
+            cache.clear()
+        cache[key] = (local_image, image, out)
+        self._stem_cache = cache
         return out
+
+    def _with_stems(self, x, t, y, concat, extra, fps):
+        B = x.shape[0]
+        ctx = y if y is not None else self.zero_y.repeat(B, 1, 1)[:, :1, :]
+        ctx = torch.cat([ctx.float(), extra.to(ctx.device)], 1)                    # text | local | global tokens
+        return self._trunk(torch.cat([x.float(), concat], 1), t, ctx, fps)
 
     @torch.no_grad()
     def forward(self, x, t, y=None, image=None, local_image=None, masked=None, fps=None, video_mask=None,
@@ -158,21 +172,21 @@ class UNetSD_I2VGen(UNetSD_T2VBase):
             raise ValueError("UNetSD_I2VGen.forward needs local_image and fps (unet_i2vgen.py:262-265,298)")
         B, C, F, H, W = x.shape
         concat, extra = self.condition_stems(local_image, image, B, F, H, W)
-        ctx = y if y is not None else self.zero_y.repeat(B, 1, 1)[:, :1, :]
-        ctx = torch.cat([ctx.float(), extra.to(ctx.device)], 1)                    # text | local | global tokens
-        return self._trunk(torch.cat([x.float(), concat], 1), t, ctx, fps)
+        return self._with_stems(x, t, y, concat, extra, fps)
 
     def forward_units(self, x, t, kwargs_list):
-        """CFG pair as one batch (see UNetSD_T2VBase.forward_units); image conditions are stacked as well."""
+        """CFG pair as one batch (see UNetSD_T2VBase.forward_units).  The stems are evaluated (and cached) per
+        unit on the caller's own conditioning tensors, then stacked."""
         G = len(kwargs_list)
-        if any(kw.get("y") is None for kw in kwargs_list):
+        if any(kw.get("y") is None or kw.get("local_image") is None or kw.get("fps") is None for kw in kwargs_list):
             return tuple(self.forward(x, t, **kw) for kw in kwargs_list)
-
-        def cat(name):
-            vals = [kw.get(name) for kw in kwargs_list]
-            return None if any(v is None for v in vals) else torch.cat([v.reshape((x.shape[0],) + tuple(v.shape[1:]))
-                                                                        if v.dim() > 1 else v.reshape(-1) for v in vals], 0)
-
-        out = self.forward(x.repeat(G, 1, 1, 1, 1), t.repeat(G), y=cat("y"), image=cat("image"),
-                           local_image=cat("local_image"), fps=cat("fps"))
+        B, C, F, H, W = x.shape
+        stems = [self.condition_stems(kw["local_image"], kw.get("image"), B, F, H, W) for kw in kwargs_list]
+        if len({s[1].shape[1] for s in stems}) != 1:
+            return tuple(self.forward(x, t, **kw) for kw in kwargs_list)
+        concat = torch.cat([s[0] for s in stems], 0)
+        extra = torch.cat([s[1] for s in stems], 0)
+        y = torch.cat([kw["y"] for kw in kwargs_list], 0)
+        fps = torch.cat([kw["fps"].reshape(-1) for kw in kwargs_list], 0)
+        out = self._with_stems(x.repeat(G, 1, 1, 1, 1), t.repeat(G), y, concat, extra, fps)
         return tuple(out.chunk(G, 0))
