@@ -127,6 +127,30 @@ def make_tft2v(R):
     print("unet_tft2v_tiny", tuple(out.shape), float(out.std()))
 
 
+VCOMPOSER = ["text", "mask", "depthmap", "sketch", "motion", "image", "local_image", "single_sketch"]
+
+
+def make_vcomposer(R):
+    """tiny UNetSD_TFT2V with the composition list of configs/tft2v_vcomposer_infer.yaml:74."""
+    import types
+    cfg = types.SimpleNamespace(video_compositions=list(VCOMPOSER), resolution=[64, 128])
+    ref = R["MODEL"].build(dict(type="UNetSD_TFT2V", config=cfg, **LCM_TINY)).eval()
+    shapes = torch_ref.shapes_of(ref)
+    ref.load_state_dict(torch_ref.synth_state_dict(shapes, seed=7), strict=True)
+    x, y = _inputs(19, 1, 3, 16, 8)
+    g = torch.Generator("cpu").manual_seed(20)
+    mk = lambda c: torch.randn(1, c, 3, 128, 64, generator=g).half().float()     # stored as fp16: exactly representable
+    conds = dict(depth=mk(1), sketch=mk(1), single_sketch=mk(1), motion=mk(2), local_image=mk(3), masked=mk(4))
+    image = torch.randn(1, 1, 1024, generator=g)
+    t = torch.tensor([601])
+    with torch.no_grad():
+        out = ref(x, t, y=y, image=image, **conds)
+    torch.save(dict(cfg=LCM_TINY, comps=list(VCOMPOSER), resolution=[64, 128], seed=7, shapes=shapes, x=x, t=t, y=y,
+                    image=image, conds={k: v.half() for k, v in conds.items()}, out=out),
+               os.path.join(GOLD, "unet_vcomposer_tiny.pt"))
+    print("unet_vcomposer_tiny", tuple(out.shape), float(out.std()))
+
+
 @torch.no_grad()
 def main():
     ap = argparse.ArgumentParser()
@@ -143,6 +167,9 @@ def main():
         return
     if args.only == "tft2v":
         make_tft2v(R)
+        return
+    if args.only == "vcomposer":
+        make_vcomposer(R)
         return
     torch.manual_seed(0)
 
@@ -228,6 +255,7 @@ def main():
     make_i2vgen(R)
     make_videolcm(R)
     make_tft2v(R)
+    make_vcomposer(R)
 
     # ---- tiny VAE ------------------------------------------------------------------------------
     vae = R["AUTO_ENCODER"].build(dict(type="AutoencoderKL", ddconfig=VAE_TINY, embed_dim=4)).eval()

@@ -233,6 +233,68 @@ def unet_i2vgen_forward(sd, x, t, y, image, local_image, fps, dim, num_tokens=4,
     return unet_forward(sd, torch.cat([x, concat], 1), t, torch.cat([y, extra], 1), dim, fps=fps)
 
 
+_COMPOSER_STEMS = (("depth", "depth_embedding", "depth_embedding_after"), ("local_image", "local_image_embedding", "local_image_embedding_after"),
+                   ("motion", "motion_embedding", "motion_embedding_after"), ("canny", "canny_embedding", "canny_embedding_after"),
+                   ("sketch", "sketch_embedding", "sketch_embedding_after"),
+                   ("single_sketch", "single_sketch_embedding", "single_sketch_embedding_after"),
+                   ("masked", "masked_embedding", "mask_embedding_after"))
+
+
+def _frame_transformer(sd, q0, s, heads=2):
+    """TransformerV2 / Transformer_v2 (util.py:1434-1453, unet_videolcm.py:121-141) on [n, f, c]."""
+    n, f, cc = s.shape
+    j = 0
+    while f"{q0}.layers.{j}.0.norm.weight" in sd:
+        q = f"{q0}.layers.{j}"
+        nn_ = F.layer_norm(s, (cc,), sd[q + ".0.norm.weight"], sd[q + ".0.norm.bias"])
+        qkv = F.linear(nn_, sd[q + ".0.fn.to_qkv.weight"])
+        inner = qkv.shape[-1] // 3
+        qh, kh, vh = [u.reshape(n, f, heads, inner // heads).transpose(1, 2) for u in qkv.split(inner, -1)]
+        att = torch.softmax(qh @ kh.transpose(-1, -2) * (inner // heads) ** -0.5, -1) @ vh
+        att = att.transpose(1, 2).reshape(n, f, inner)
+        s = F.linear(att, sd[q + ".0.fn.to_out.0.weight"], sd[q + ".0.fn.to_out.0.bias"]) + s
+        m = F.gelu(F.linear(s, sd[q + ".1.net.0.0.weight"], sd[q + ".1.net.0.0.bias"]))
+        s = F.linear(m, sd[q + ".1.net.2.weight"], sd[q + ".1.net.2.bias"]) + s
+        j += 1
+    return s
+
+
+def composer_concat(sd, conds, resolution, b):
+    """Sum of the spatial composition stems, unet_videolcm.py:598-699 (eval: misc_dropout is the identity), in
+    the reference's order of accumulation."""
+    concat = None
+    for kwarg, stem, after in _COMPOSER_STEMS:
+        c = conds.get(kwarg)
+        if c is None:
+            continue
+        bc, ch, f, hh, ww = c.shape
+        z = c.permute(0, 2, 1, 3, 4).reshape(bc * f, ch, hh, ww)
+        z = F.silu(F.conv2d(z, sd[stem + ".0.weight"], sd[stem + ".0.bias"], padding=1))
+        z = F.adaptive_avg_pool2d(z, (resolution[1] // 2, resolution[0] // 2))
+        z = F.silu(F.conv2d(z, sd[stem + ".3.weight"], sd[stem + ".3.bias"], stride=2, padding=1))
+        z = F.conv2d(z, sd[stem + ".5.weight"], sd[stem + ".5.bias"], stride=2, padding=1)
+        cd, h, w = z.shape[1:]
+        sq = z.reshape(b, f, cd, h, w).permute(0, 3, 4, 1, 2).reshape(b * h * w, f, cd)
+        sq = _frame_transformer(sd, after, sq)
+        z5 = sq.reshape(b, h, w, f, cd).permute(0, 4, 3, 1, 2)
+        concat = z5 if concat is None else concat + z5
+    return concat
+
+
+def unet_composer_forward(sd, x, t, y, dim, concat_dim, resolution, image=None, num_tokens=4, context_dim=1024, **conds):
+    """UNetSD_VideoLCM / UNetSD_TFT2V.forward with spatial compositions (no histogram)."""
+    b, c, f, h, w = x.shape
+    concat = composer_concat(sd, conds, resolution, b)
+    if concat is None:
+        concat = x.new_zeros(b, concat_dim, f, h, w)
+    ctx = y
+    if image is not None:
+        ic = F.linear(F.silu(F.linear(image, sd["pre_image_condition.0.weight"], sd["pre_image_condition.0.bias"])),
+                      sd["pre_image_condition.2.weight"], sd["pre_image_condition.2.bias"])
+        ctx = torch.cat([ctx, ic.reshape(-1, num_tokens, context_dim)], 1)
+    return unet_forward(sd, torch.cat([x, concat], 1), t, ctx, dim)
+
+
 def unet_videolcm_text_forward(sd, x, t, y, dim, concat_dim, image=None, num_tokens=4, context_dim=1024):
     """UNetSD_VideoLCM / UNetSD_TFT2V.forward with video_compositions within ['text', 'image']
     (unet_videolcm.py:598, 702-705, 709-784; unet_tf2tv.py likewise): zero concat buffer, identity pre_image,

@@ -223,10 +223,10 @@ def test_videolcm_text_oracle_and_host_logic_vs_reference_golden(emu_backend):
     m.load_state_dict(sd, strict=True)
     out = m(g["x"], g["t"], y=g["y"])                       # float timesteps, like the LCM engine
     assert out.shape == g["out"].shape and rel_l2(out, g["out"]) < 3e-3
-    with pytest.raises(NotImplementedError):
-        m(g["x"], g["t"], y=g["y"], depth=torch.zeros(1))
-    with pytest.raises(NotImplementedError):
-        UNetSD_VideoLCM(config=types.SimpleNamespace(video_compositions=["text", "depthmap"], resolution=[64, 128]),
+    with pytest.raises(ValueError):                           # not one of this model's compositions
+        m(g["x"], g["t"], y=g["y"], depth=torch.zeros(1, 1, 4, 128, 64))
+    with pytest.raises(NotImplementedError):                  # per-frame context tokens are not supported
+        UNetSD_VideoLCM(config=types.SimpleNamespace(video_compositions=["text", "histogram"], resolution=[64, 128]),
                         **g["cfg"])
 
 
@@ -248,3 +248,30 @@ def test_tft2v_text_image_oracle_and_host_logic_vs_reference_golden(emu_backend)
     kw2 = dict(y=torch.roll(g["y"], 1, 1), image=g["image"] * 0.5)
     a, b = m.forward_units(g["x"], g["t"], [kw, kw2])
     assert rel_l2(a, out) < 1e-5 and rel_l2(b, m(g["x"], g["t"], **kw2)) < 1e-5
+
+
+def test_vcomposer_spatial_stems_oracle_and_host_logic_vs_reference_golden(emu_backend):
+    """UNetSD_TFT2V with the composition list of configs/tft2v_vcomposer_infer.yaml:74 (mask, depthmap, sketch, motion,
+    image, local_image, single_sketch)."""
+    import types
+    from vgen_amd.unet_videolcm import UNetSD_TFT2V, UNetSD_VideoLCM
+    g = gold("unet_vcomposer_tiny.pt")
+    sd = torch_ref.synth_state_dict(g["shapes"], seed=g["seed"])
+    conds = {k: v.float() for k, v in g["conds"].items()}
+    ref = torch_ref.unet_composer_forward(sd, g["x"], g["t"], g["y"], g["cfg"]["dim"], g["cfg"]["concat_dim"],
+                                          g["resolution"], image=g["image"], **conds)
+    assert rel_l2(ref, g["out"]) < 2e-5
+    cfg = types.SimpleNamespace(video_compositions=g["comps"], resolution=g["resolution"])
+    for cls in (UNetSD_TFT2V, UNetSD_VideoLCM):            # same trunk, same parameter set
+        m = cls(config=cfg, **g["cfg"], compute_dtype="fp16").eval()
+        assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v) for k, v in g["shapes"].items()}
+    m.load_state_dict(sd, strict=True)
+    out = m(g["x"], g["t"], y=g["y"], image=g["image"], **conds)
+    assert out.shape == g["out"].shape and rel_l2(out, g["out"]) < 3e-3
+    n = len(m._stem_cache)
+    m(g["x"] * 0.9, g["t"], y=g["y"], image=g["image"], **conds)          # next denoise step: stems come from the cache
+    assert len(m._stem_cache) == n == 6
+    with pytest.raises(NotImplementedError):
+        m(g["x"], g["t"], y=g["y"], histogram=torch.zeros(1))
+    with pytest.raises(ValueError):
+        m(g["x"], g["t"], y=g["y"], canny=conds["depth"])               # 'canny' is not in this model's compositions

@@ -6,9 +6,11 @@ With only the text (and optionally the global-image) composition the reference b
 stem: `pre_image` is an empty Sequential (:409), the `concat` buffer stays zero (:598) and the context is the
 text tokens (:714-741) plus, with 'image', num_tokens tokens from `pre_image_condition` (:284-288, 743-745).
 The forward is then the t2v trunk behind a stem conv with `in_dim + concat_dim` input channels of which the
-last `concat_dim` see zeros.  The spatial compositions (depth / sketch / motion / local_image / histogram ...
-stems, :294-372, 598-699) are not built here: asking for them raises NotImplementedError (SURVEY §8 f2,
-"next").  `UNetSD_TFT2V` (unet_tf2tv.py) is the same class without the unused t_w argument.
+last `concat_dim` see zeros.  The spatial compositions (depthmap / motion / canny / mask / sketch / single_sketch /
+local_image, :294-372, 598-699) each add a `concat_dim`-channel map into that buffer; their stems depend only on
+the conditioning maps, so they are evaluated once per conditioning tensor with torch modules and cached (prompt
+constants ahead of the hot path, like UNetSD_I2VGen's).  'histogram' adds a different context token per FRAME,
+which does not fit the per-prompt K/V layout of the native trunk: NotImplementedError.  `UNetSD_TFT2V` (unet_tf2tv.py) is the same class without the unused t_w argument.
 The LCM sampler passes float timesteps (inference_videolcm_entrance.py:239); `vgen_timestep_embedding` takes
 fp32 t, so those work unchanged.
 """
@@ -20,9 +22,22 @@ import torch.nn as nn
 
 from . import ops
 from .unet import UNetSD_T2VBase, _f32, pack_linear
+from .unet_i2vgen import _FrameTransformer
 
-_UNSUPPORTED = ("depth", "motion", "local_image", "single_sketch", "masked", "canny", "sketch", "histogram")
-_SUPPORTED_COMPOSITIONS = ("text", "image")
+# spatial compositions: composition name -> (forward kwarg, stem attribute, transformer attribute, input channels)
+# (unet_videolcm.py:294-372 / unet_tf2tv.py likewise; every stem is Conv3x3 - SiLU - AdaptiveAvgPool(res/2) -
+#  Conv3x3 s2 - SiLU - Conv3x3 s2 -> concat_dim channels at latent resolution, then one Transformer_v2 over frames)
+_SPATIAL = {
+    "depthmap": ("depth", "depth_embedding", "depth_embedding_after", 1),
+    "motion": ("motion", "motion_embedding", "motion_embedding_after", 2),
+    "canny": ("canny", "canny_embedding", "canny_embedding_after", 1),
+    "mask": ("masked", "masked_embedding", "mask_embedding_after", 4),
+    "sketch": ("sketch", "sketch_embedding", "sketch_embedding_after", 1),
+    "single_sketch": ("single_sketch", "single_sketch_embedding", "single_sketch_embedding_after", 1),
+    "local_image": ("local_image", "local_image_embedding", "local_image_embedding_after", 3),
+}
+_UNSUPPORTED = ("histogram",)
+_SUPPORTED_COMPOSITIONS = ("text", "image") + tuple(_SPATIAL)
 
 
 def _compositions(config):
@@ -41,17 +56,38 @@ class _ComposerTrunk(UNetSD_T2VBase):
     def _extra_stem_channels(kwargs):
         return kwargs["_composer_concat"]
 
-    def _init_composer(self, config, concat_dim, num_tokens, black_image_feature):
+    def _init_composer(self, config, concat_dim, num_tokens, black_image_feature, inpainting, adapter_layers):
         self.cfg = config
         self.concat_dim = concat_dim
         self.num_tokens = num_tokens
         self.video_compositions = _compositions(config)
         self.black_image_feature = black_image_feature
+        res = getattr(config, "resolution", None) or (config.get("resolution") if isinstance(config, dict) else None)
+        self.resolution = res
         if "image" in self.video_compositions:
             cd = self.context_dim
             self.pre_image_condition = nn.Sequential(nn.Linear(cd, cd), nn.SiLU(), nn.Linear(cd, cd * num_tokens))
+        # spatial condition stems: prompt constants (they depend on the conditioning maps only), evaluated once per
+        # conditioning tensor with torch modules and cached — like UNetSD_I2VGen's; registered in the reference's
+        # order and under its names so stock checkpoints load strict
+        c4 = concat_dim * 4
+        for name in ("depthmap", "motion", "canny", "mask", "sketch", "single_sketch", "local_image"):
+            if name not in self.video_compositions:
+                continue
+            kwarg, stem, after, cin = _SPATIAL[name]
+            if res is None:
+                raise ValueError(f"{type(self).__name__}: config.resolution is needed for the '{name}' stem")
+            if name == "mask" and not inpainting:
+                setattr(self, stem, None)
+            else:
+                setattr(self, stem, nn.Sequential(
+                    nn.Conv2d(cin, c4, 3, padding=1), nn.SiLU(), nn.AdaptiveAvgPool2d((res[1] // 2, res[0] // 2)),
+                    nn.Conv2d(c4, c4, 3, stride=2, padding=1), nn.SiLU(), nn.Conv2d(c4, concat_dim, 3, stride=2, padding=1)))
+            setattr(self, after, _FrameTransformer(heads=2, dim=concat_dim, dim_head=concat_dim, mlp_dim=concat_dim,
+                                                   depth=adapter_layers))
         self._zeros = None
         self._pic = None
+        self._stem_cache = {}
 
     @staticmethod
     def _check(config, name):
@@ -65,6 +101,7 @@ class _ComposerTrunk(UNetSD_T2VBase):
     def pack(self, device=None):
         super().pack(device)
         self._pic = None
+        self._stem_cache = {}
 
     def _image_tokens(self, image, B):
         be, dt = ops.backend(), self.compute_dtype
@@ -77,23 +114,59 @@ class _ComposerTrunk(UNetSD_T2VBase):
         return o.view(B, self.num_tokens, self.context_dim)
 
     @torch.no_grad()
+    def _spatial_stem(self, name, cond, B):
+        """One composition's contribution to the concat buffer (:600-699): [B, c, F, Hc, Wc] -> [B, concat_dim, F, h, w].
+        Cached per conditioning tensor object (+ version), holding a reference (see UNetSD_I2VGen.condition_stems)."""
+        key = (name, id(cond), cond._version)
+        hit = self._stem_cache.get(key)
+        if hit is not None and hit[0] is cond:
+            return hit[1]
+        kwarg, stem, after, cin = _SPATIAL[name]
+        Bc, c, F, Hc, Wc = cond.shape
+        z = getattr(self, stem)(cond.float().permute(0, 2, 1, 3, 4).reshape(Bc * F, c, Hc, Wc))     # [(B F), cd, h, w]
+        cd, h, w = z.shape[1:]
+        seq = z.view(Bc, F, cd, h, w).permute(0, 3, 4, 1, 2).reshape(Bc * h * w, F, cd)
+        seq = getattr(self, after)(seq)
+        out = seq.view(Bc, h, w, F, cd).permute(0, 4, 3, 1, 2).contiguous()
+        if len(self._stem_cache) >= 32:
+            self._stem_cache.clear()
+        self._stem_cache[key] = (cond, out)
+        return out
+
+    @torch.no_grad()
     def forward(self, x, t, t_w=None, y=None, image=None, fps=None, video_mask=None, focus_present_mask=None,
                 prob_focus_present=0., mask_last_frame_num=0, **conds):
         given = [k for k in _UNSUPPORTED if conds.get(k) is not None]
         if given:
-            raise NotImplementedError(f"{type(self).__name__}: conditions {given} need the native stems (SURVEY §8 f2)")
+            raise NotImplementedError(f"{type(self).__name__}: conditions {given}: a per-frame context token does not "
+                                      "fit the per-prompt K/V layout of the native trunk (SURVEY §8 f2)")
         if self._packed is None:
             self.pack()
         B, C, F, H, W = x.shape
-        shape = (B, self.concat_dim, F, H, W)
-        if self._zeros is None or self._zeros.shape != shape or self._zeros.device != x.device:
-            self._zeros = torch.zeros(shape, dtype=torch.float32, device=x.device)
+        concat = None
+        for name, (kwarg, stem, after, cin) in _SPATIAL.items():        # the reference's order of accumulation
+            cond = conds.get(kwarg)
+            if cond is None:
+                continue
+            if name not in self.video_compositions:
+                raise ValueError(f"condition '{kwarg}' given but '{name}' is not in video_compositions")
+            c = self._spatial_stem(name, cond, B)
+            concat = c if concat is None else concat + c
+        unknown = [k for k, v in conds.items() if v is not None and k not in [a[0] for a in _SPATIAL.values()]
+                   and k not in _UNSUPPORTED]
+        if unknown:
+            raise TypeError(f"{type(self).__name__}.forward: unexpected arguments {unknown}")
+        if concat is None:
+            shape = (B, self.concat_dim, F, H, W)
+            if self._zeros is None or self._zeros.shape != shape or self._zeros.device != x.device:
+                self._zeros = torch.zeros(shape, dtype=torch.float32, device=x.device)
+            concat = self._zeros
         ctx = y if y is not None else self.zero_y.repeat(B, 1, 1)          # full zero_y here (:740)
         if image is not None:
             if "image" not in self.video_compositions:
                 raise ValueError("image condition given but 'image' is not in video_compositions")
             ctx = torch.cat([ctx.float(), self._image_tokens(image, B).to(ctx.device)], 1)
-        return self._trunk(torch.cat([x.float(), self._zeros], 1), t, ctx, fps)
+        return self._trunk(torch.cat([x.float(), concat.to(x.device)], 1), t, ctx, fps)
 
     def forward_units(self, x, t, kwargs_list):
         G = len(kwargs_list)
@@ -130,7 +203,7 @@ class UNetSD_VideoLCM(_ComposerTrunk):
                  use_lcm=True, compute_dtype=None, **kwargs):
         self._check(config, "UNetSD_VideoLCM")
         super().__init__(**_trunk_kwargs(locals()), _composer_concat=concat_dim, **kwargs)
-        self._init_composer(config, concat_dim, num_tokens, black_image_feature)
+        self._init_composer(config, concat_dim, num_tokens, black_image_feature, inpainting, adapter_transformer_layers)
 
 
 class UNetSD_TFT2V(_ComposerTrunk):
@@ -146,4 +219,4 @@ class UNetSD_TFT2V(_ComposerTrunk):
                  compute_dtype=None, **kwargs):
         self._check(config, "UNetSD_TFT2V")
         super().__init__(**_trunk_kwargs(locals()), _composer_concat=concat_dim, **kwargs)
-        self._init_composer(config, concat_dim, num_tokens, black_image_feature)
+        self._init_composer(config, concat_dim, num_tokens, black_image_feature, inpainting, adapter_transformer_layers)
