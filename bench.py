@@ -12,14 +12,19 @@ random-init weights (no checkpoints offline).
 
 N > 1 (weak scaling): P = N prompts in flight -> 2N units spread over the ranks (unit u -> rank
 u % N), ONE all-gather of the unit outputs per step (RCCL), every rank applies the cheap update for
-all prompts.  value = prompts * steps / max-over-ranks time.
+all prompts.  value = prompts * steps / max-over-ranks time.  The local units' forward is replayed as a
+hipGraph (vgen_amd.graph.GraphedForward); the all-gather and the update stay eager.  `--partition`
+runs that same code path at N = 1.
 
 Extra objects on the JSON line:
   roofline     — dominant kernel (tap-GEMM, MFMA-bound): algorithmic FLOP per launch / average launch
                  duration, measured with HIP events on the launch stream in an instrumented pass of
                  the same step; peak = 2.5 PFLOP/s dense 16-bit MFMA.
+                 `traffic` = HBM-side bytes per launch from the committed rocprofv3 PMC passes of this
+                 command (profiles/r01_tapgemm_traffic.json; tools/collect_evidence.sh regenerates them).
   cpu_baseline — the oracle (CPU port of the reference forward, oracle/torch_ref.py) timed on the
-                 host cores on ONE full-size UNet forward (= half a denoise step), rank 0 at N=1.
+                 host cores on a bounded sample (full-size UNet, 4-frame latent, 32 threads), scaled to
+                 a full step; rank 0 at N=1.
   vae          — AutoencoderKL decode frames/s at 256x448 (decoder_bs = 2 like t2v_infer.yaml).
 """
 from __future__ import annotations

@@ -6,23 +6,25 @@
 //     channels-last row layout every tap's K-slab is one contiguous C-length row of a shifted
 //     pixel / frame, so a conv A-tile is a row GATHER of 128-byte pieces — no im2col buffer,
 //     no torch.cat, no F.interpolate, no rearrange.
-//   * 512 threads = 8 waves (4 along M x 2 along N), ONE block per CU.  Block tile 256 x BN with
-//     BK = 64; BN = 128 (N % 128 == 0), 160 (N = 320 / 960 ...: exact tiles instead of 2.5 x 128)
-//     or 64 (small / odd N).  Each wave owns a 64 x (BN/2) sub-tile of 16x16x32 MFMA fragments.
-//     256-row tiles halve the L2->LDS bytes per flop of a 128x128 tile (85-98 flop/B).
+//   * one kernel template, three block shapes chosen per launch by make_plan() (table further down):
+//     "pp" 256 x BN, BK 64, 8 waves, one block per CU, ping-pong wave groups; "dual" 256 x BN, BK 32,
+//     4 waves with 128-row wave tiles, two blocks per CU; "pp128" 128 x BN for under-filled launches.
+//     BN = 128 (N % 128 == 0), 160 (N = 320 / 960 ...: exact tiles instead of 2.5 x 128) or 64
+//     (small / odd N); 16x16x32 MFMA fragments.  256-row tiles halve the L2->LDS bytes per flop of a
+//     128 x 128 tile (85-98 flop/B).
 //   * operands swapped on the matrix core: D[i = n][j = m] = sum_k W[n,k] * A[m,k].  The
 //     C/D fragment then holds 4 CONSECUTIVE n for one m per lane -> bias / residual / output
 //     move as one 16-byte (fp32) or 8-byte (16-bit) vector per fragment.
 //   * global -> LDS staging by LDS-DMA (`global_load_lds_dwordx4`, 1 KiB = 8 tile rows per
 //     wave-instruction): no staging VGPRs, no ds_write pass.  THREE-stage ring (up to 156 KiB of
-//     the 160 KiB LDS), one raw s_barrier per K-tile, COUNTED vmcnt: while tile t is multiplied
+//     the 160 KiB LDS), raw s_barriers, COUNTED vmcnt: while tile t is multiplied
 //     the DMAs of tiles t+1 and t+2 stay in flight across the barrier (~100 KiB in flight per CU,
 //     what Little's law asks for at ~1 us of loaded L2/MALL latency).  v1 (register staging,
 //     2 stages) was LDS-write bound, v2 (DMA, 2 stages, vmcnt(0) + __syncthreads) spent 40-50 %
 //     of its wave cycles parked at the wait (profiles/).
 //     Out-of-range rows (conv padding, M/N tails) read a 16-byte zero line instead.
-//   * LDS tiles are [rows][64] 16-bit (128 B / row).  The DMA destination is lane-linear, so the
-//     XOR swizzle (chunk ^ (row & 7)) is applied on the per-lane SOURCE address and again on the
+//   * LDS tiles are [rows][BK] 16-bit (128 or 64 B / row).  The DMA destination is lane-linear, so
+//     the bank swizzle (swz_key below) is applied on the per-lane SOURCE address and again on the
 //     fragment reads: ds_read_b128 of a fragment (16 rows x one chunk per 16-lane group) is
 //     bank-conflict free (SQ_LDS_BANK_CONFLICT = 0 measured).
 //   * XCD-aware tile order: block b runs on XCD b % 8; tiles are renumbered so that each XCD works
@@ -31,7 +33,8 @@
 //     partial fp32 tiles go to a caller workspace and a small second kernel reduces them in a
 //     fixed order (deterministic) and applies the epilogue.
 //   * fp32 accumulate; epilogue in fp32: + bias + per-image row-bias (time embedding)
-//     + fp32 residual, optional GEGLU gate, fp32 or 16-bit store.
+//     + fp32 residual, optional GEGLU gate, fp32 or 16-bit store, optional per-64-row-slab column
+//     statistics for the GroupNorm that consumes the output.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
