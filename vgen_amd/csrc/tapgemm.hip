@@ -36,6 +36,7 @@
 //     + fp32 residual, optional GEGLU gate, fp32 or 16-bit store, optional per-64-row-slab column
 //     statistics for the GroupNorm that consumes the output.
 #include "common.h"
+#include <stdio.h>
 #include <stdlib.h>
 #include <type_traits>
 
@@ -626,6 +627,17 @@ int env_int(const char* name, int dflt) {
   return v ? atoi(v) : dflt;
 }
 
+// Measured plans for the launches of the reference's t2v UNet at its benchmark shape (tools/autotune_gemm.py
+// times every (shape, BN, split-K) candidate per distinct launch signature on the GPU and writes this table):
+// consulted before the cost model, which stays the rule for every other shape.
+struct PlanEntry {
+  int mode;
+  int64_t M;
+  int N, C1, C2, taps, epilogue, out_dtype, flags;   // flags: residual | rowbias << 1 | colstats << 2
+  int shape, bn, splitk;
+};
+#include "tapgemm_plans.inc"
+
 Plan make_plan(const vgen_tapgemm_args& a) {
   const bool geglu = a.epilogue == VGEN_EPI_GEGLU;
   const int KT = a.taps * (a.C1 / 64) + a.C2 / 64;
@@ -643,6 +655,27 @@ Plan make_plan(const vgen_tapgemm_args& a) {
   // HBM time of the epilogue traffic (output + fp32 residual), not hidden behind MFMAs when every CU
   // runs one block in the same phase ("pp"); about half hidden with two independent blocks per CU
   const double epi_us = (double)a.M * n_out * ((a.out_dtype == VGEN_F32 ? 4 : 2) + (a.residual ? 4 : 0)) / 4.5e6;
+  auto legal = [&](int shape, int bn, int sk) {
+    bool ok = false;
+    for (int c = 0; c < nc; ++c) ok |= cands[c] == bn;
+    return ok && shape >= SHAPE_PP && shape <= SHAPE_PP128 && sk >= 1 && sk <= (smax < 1 ? 1 : smax) &&
+           !(a.colstats && shape == SHAPE_PP128);
+  };
+  // tuning switches (not part of the ABI): VGEN_TAPGEMM_PLAN="shape,bn,splitk" forces one plan (read on every
+  // call: the autotuner flips it between launches); VGEN_TAPGEMM_TABLE=0 ignores the measured table
+  if (const char* fp = getenv("VGEN_TAPGEMM_PLAN")) {
+    int sh = -1, bn = 0, sk = 0;
+    if (sscanf(fp, "%d,%d,%d", &sh, &bn, &sk) == 3 && legal(sh, bn, sk)) return Plan{sh, bn, sk};
+  }
+  static const bool use_table = env_int("VGEN_TAPGEMM_TABLE", 1) != 0;
+  if (use_table && force_shape < 0) {
+    const int flags = (a.residual ? 1 : 0) | (a.rowbias ? 2 : 0) | (a.colstats ? 4 : 0);
+    for (const PlanEntry& e : kPlans) {
+      if (e.mode == a.mode && e.M == a.M && e.N == a.N && e.C1 == a.C1 && e.C2 == a.C2 && e.taps == a.taps &&
+          e.epilogue == a.epilogue && e.out_dtype == a.out_dtype && e.flags == flags && legal(e.shape, e.bn, e.splitk))
+        return Plan{e.shape, e.bn, e.splitk};
+    }
+  }
   Plan best{SHAPE_PP, cands[0], 1};
   double best_cost = 1e30;
   for (int shape = SHAPE_PP; shape <= SHAPE_PP128; ++shape) {
