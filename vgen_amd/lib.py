@@ -97,6 +97,11 @@ def load(path: str | None = None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # PyTorch owns the device memory and the streams this library enqueues on, so both must run on ONE HIP
+    # runtime: import torch first.  Its wheel bundles its own libamdhip64; loaded after /opt/rocm's copy (which a
+    # bare CDLL of libvgen_hip.so would pull in) the process ends up with two runtimes and every launch from this
+    # library fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     if not os.path.exists(p):
         raise VgenHipError(
             f"{p} not found: build it with `python -m vgen_amd.build` (hipcc, gfx950). "
