@@ -127,6 +127,26 @@ def make_tft2v(R):
     print("unet_tft2v_tiny", tuple(out.shape), float(out.std()))
 
 
+def make_histogram(R):
+    """tiny UNetSD_VideoLCM with a per-frame context token: video_compositions ['text', 'histogram', 'canny']."""
+    import types
+    comps = ["text", "histogram", "canny"]
+    cfg = types.SimpleNamespace(video_compositions=comps, resolution=[64, 128])
+    ref = R["MODEL"].build(dict(type="UNetSD_VideoLCM", config=cfg, **LCM_TINY)).eval()
+    shapes = torch_ref.shapes_of(ref)
+    ref.load_state_dict(torch_ref.synth_state_dict(shapes, seed=8), strict=True)
+    x, y = _inputs(23, 2, 3, 16, 8)
+    g = torch.Generator("cpu").manual_seed(24)
+    hist = torch.rand(2, 3, 156, generator=g)
+    canny = torch.randn(2, 1, 3, 128, 64, generator=g).half().float()
+    t = torch.tensor([759.0, 259.0])
+    with torch.no_grad():
+        out = ref(x, t, y=y, histogram=hist, canny=canny)
+    torch.save(dict(cfg=LCM_TINY, comps=comps, resolution=[64, 128], seed=8, shapes=shapes, x=x, t=t, y=y,
+                    histogram=hist, canny=canny.half(), out=out), os.path.join(GOLD, "unet_histogram_tiny.pt"))
+    print("unet_histogram_tiny", tuple(out.shape), float(out.std()))
+
+
 VCOMPOSER = ["text", "mask", "depthmap", "sketch", "motion", "image", "local_image", "single_sketch"]
 
 
@@ -170,6 +190,9 @@ def main():
         return
     if args.only == "vcomposer":
         make_vcomposer(R)
+        return
+    if args.only == "histogram":
+        make_histogram(R)
         return
     torch.manual_seed(0)
 
@@ -256,6 +279,7 @@ def main():
     make_videolcm(R)
     make_tft2v(R)
     make_vcomposer(R)
+    make_histogram(R)
 
     # ---- tiny VAE ------------------------------------------------------------------------------
     vae = R["AUTO_ENCODER"].build(dict(type="AutoencoderKL", ddconfig=VAE_TINY, embed_dim=4)).eval()

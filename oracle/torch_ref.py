@@ -281,8 +281,9 @@ def composer_concat(sd, conds, resolution, b):
     return concat
 
 
-def unet_composer_forward(sd, x, t, y, dim, concat_dim, resolution, image=None, num_tokens=4, context_dim=1024, **conds):
-    """UNetSD_VideoLCM / UNetSD_TFT2V.forward with spatial compositions (no histogram)."""
+def unet_composer_forward(sd, x, t, y, dim, concat_dim, resolution, image=None, num_tokens=4, context_dim=1024,
+                          histogram=None, **conds):
+    """UNetSD_VideoLCM / UNetSD_TFT2V.forward with any composition list (unet_videolcm.py:541-784)."""
     b, c, f, h, w = x.shape
     concat = composer_concat(sd, conds, resolution, b)
     if concat is None:
@@ -292,6 +293,11 @@ def unet_composer_forward(sd, x, t, y, dim, concat_dim, resolution, image=None, 
         ic = F.linear(F.silu(F.linear(image, sd["pre_image_condition.0.weight"], sd["pre_image_condition.0.bias"])),
                       sd["pre_image_condition.2.weight"], sd["pre_image_condition.2.bias"])
         ctx = torch.cat([ctx, ic.reshape(-1, num_tokens, context_dim)], 1)
+    if histogram is not None:                            # one more token per frame (:747-755)
+        hc = F.linear(F.silu(F.linear(histogram, sd["hist_context_embedding.0.weight"], sd["hist_context_embedding.0.bias"])),
+                      sd["hist_context_embedding.2.weight"], sd["hist_context_embedding.2.bias"])
+        ctx = torch.cat([ctx.repeat_interleave(repeats=f, dim=0), hc.reshape(b * f, 1, context_dim)], 1)
+        return unet_forward(sd, torch.cat([x, concat], 1), t, ctx, dim, context_per_frame=True)
     return unet_forward(sd, torch.cat([x, concat], 1), t, ctx, dim)
 
 
@@ -308,7 +314,7 @@ def unet_videolcm_text_forward(sd, x, t, y, dim, concat_dim, image=None, num_tok
     return unet_forward(sd, torch.cat([x, x.new_zeros(b, concat_dim, f, h, w)], 1), t, ctx, dim)
 
 
-def unet_forward(sd, x, t, y, dim, down_padding=1, up_crop=0, freeu=None, fps=None):
+def unet_forward(sd, x, t, y, dim, down_padding=1, up_crop=0, freeu=None, fps=None, context_per_frame=False):
     """UNetSD_T2VBase.forward / _forward_single, unet/unet_t2v.py:210-348 (y given; `fps` adds the
     fps embedding, :244-245 / unet_i2vgen.py:298).  The block structure is recovered from the state_dict keys."""
     b, c, f, h, w = x.shape
@@ -318,7 +324,7 @@ def unet_forward(sd, x, t, y, dim, down_padding=1, up_crop=0, freeu=None, fps=No
         e2 = F.linear(sinusoidal_embedding(fps, dim), sd["fps_embedding.0.weight"], sd["fps_embedding.0.bias"])
         emb = emb + F.linear(F.silu(e2), sd["fps_embedding.2.weight"], sd["fps_embedding.2.bias"])
     emb = emb.repeat_interleave(repeats=f, dim=0)
-    context = y.repeat_interleave(repeats=f, dim=0)
+    context = y if context_per_frame else y.repeat_interleave(repeats=f, dim=0)     # [(b f), L, D]
     x = x.permute(0, 2, 1, 3, 4).reshape(b * f, c, h, w)
 
     def run(p, x):

@@ -225,8 +225,8 @@ def test_videolcm_text_oracle_and_host_logic_vs_reference_golden(emu_backend):
     assert out.shape == g["out"].shape and rel_l2(out, g["out"]) < 3e-3
     with pytest.raises(ValueError):                           # not one of this model's compositions
         m(g["x"], g["t"], y=g["y"], depth=torch.zeros(1, 1, 4, 128, 64))
-    with pytest.raises(NotImplementedError):                  # per-frame context tokens are not supported
-        UNetSD_VideoLCM(config=types.SimpleNamespace(video_compositions=["text", "histogram"], resolution=[64, 128]),
+    with pytest.raises(NotImplementedError):                  # unknown composition names are refused loudly
+        UNetSD_VideoLCM(config=types.SimpleNamespace(video_compositions=["text", "zebra"], resolution=[64, 128]),
                         **g["cfg"])
 
 
@@ -271,7 +271,26 @@ def test_vcomposer_spatial_stems_oracle_and_host_logic_vs_reference_golden(emu_b
     n = len(m._stem_cache)
     m(g["x"] * 0.9, g["t"], y=g["y"], image=g["image"], **conds)          # next denoise step: stems come from the cache
     assert len(m._stem_cache) == n == 6
-    with pytest.raises(NotImplementedError):
-        m(g["x"], g["t"], y=g["y"], histogram=torch.zeros(1))
+    with pytest.raises(ValueError):
+        m(g["x"], g["t"], y=g["y"], histogram=torch.zeros(1, 3, 156))  # not in this model's compositions
     with pytest.raises(ValueError):
         m(g["x"], g["t"], y=g["y"], canny=conds["depth"])               # 'canny' is not in this model's compositions
+
+
+def test_histogram_per_frame_context_oracle_and_host_logic_vs_reference_golden(emu_backend):
+    """video_compositions ['text', 'histogram', 'canny']: one extra context token PER FRAME -> K/V projected per
+    (prompt, frame) and addressed frame-major by the cross-attention strides."""
+    import types
+    from vgen_amd.unet_videolcm import UNetSD_VideoLCM
+    g = gold("unet_histogram_tiny.pt")
+    sd = torch_ref.synth_state_dict(g["shapes"], seed=g["seed"])
+    canny = g["canny"].float()
+    ref = torch_ref.unet_composer_forward(sd, g["x"], g["t"], g["y"], g["cfg"]["dim"], g["cfg"]["concat_dim"],
+                                          g["resolution"], histogram=g["histogram"], canny=canny)
+    assert rel_l2(ref, g["out"]) < 2e-5
+    cfg = types.SimpleNamespace(video_compositions=g["comps"], resolution=g["resolution"])
+    m = UNetSD_VideoLCM(config=cfg, **g["cfg"], compute_dtype="fp16").eval()
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v) for k, v in g["shapes"].items()}
+    m.load_state_dict(sd, strict=True)
+    out = m(g["x"], g["t"], y=g["y"], histogram=g["histogram"], canny=canny)
+    assert out.shape == g["out"].shape and rel_l2(out, g["out"]) < 3e-3

@@ -462,7 +462,7 @@ class UNetSD_T2VBase(nn.Module):
         # FF output is only consumed by proj_out -> emit it 16-bit (sum formed in fp32)
         return self._linear(g, P["ff2"], M, residual=x, out_dtype=dt)
 
-    def _spatial_tx(self, st: _SpatialTransformerP, x, kv_all, B, F, H, W, Lctx):
+    def _spatial_tx(self, st: _SpatialTransformerP, x, kv_all, B, F, H, W, Lctx, kv_per_frame=False):
         """reference: SpatialTransformer.forward (util.py:354-373)."""
         be = ops.backend()
         dt = self.compute_dtype
@@ -488,10 +488,13 @@ class UNetSD_T2VBase(nn.Module):
             kw = kv_all.shape[1]
             k = kv_all[:, st._kv_off: st._kv_off + d]
             v = kv_all[:, st._kv_off + d: st._kv_off + 2 * d]
+            # K/V rows are per prompt (every frame of a video reads the same 77 context rows: no x F repeat,
+            # unet_t2v.py:255) or, when a composition adds a per-frame token (histogram), per (prompt, frame)
+            kvs = (kw, F * Lctx * kw, Lctx * kw) if kv_per_frame else (kw, Lctx * kw, 0)
             return be.attention(Attn(q=q, k=k, v=v, out=out, heads=heads, nq=N, nk=Lctx,
                                      nbatch=B * F, inner=F,
-                                     q_s=(d, F * N * d, N * d), k_s=(kw, Lctx * kw, 0),
-                                     v_s=(kw, Lctx * kw, 0), o_s=(d, F * N * d, N * d), scale=scale))
+                                     q_s=(d, F * N * d, N * d), k_s=kvs,
+                                     v_s=kvs, o_s=(d, F * N * d, N * d), scale=scale))
 
         t = self._tblock(P["tb"], tok, M, d, heads, attn1, attn2)
         return self._linear(t, P["pout"], M, residual=x, colstats=True)
@@ -546,9 +549,10 @@ class UNetSD_T2VBase(nn.Module):
         ctx = y if y is not None else self.zero_y.repeat(x.shape[0], 1, 1)[:, :1, :]
         return self._trunk(x, t, ctx, fps)
 
-    def _trunk(self, x, t, ctx, fps=None):
+    def _trunk(self, x, t, ctx, fps=None, ctx_per_frame=False):
         """Embeddings + encoder / middle / decoder / head on rows (unet_t2v.py:241-277).  `x` carries every
-        input channel of the stem conv ([B, C, F, H, W]), `ctx` every cross-attention token ([B, L, 1024])."""
+        input channel of the stem conv ([B, C, F, H, W]), `ctx` every cross-attention token: [B, L, 1024] shared
+        by the frames of a video, or [B * F, L, 1024] with ctx_per_frame (frame-major per prompt)."""
         be = ops.backend()
         dt = self.compute_dtype
         if self._packed is None:
@@ -573,8 +577,10 @@ class UNetSD_T2VBase(nn.Module):
         emb_all = self._linear(es, P["emb_all"], B)                 # [B, sum(Cout)] fp32
 
         Lctx = ctx.shape[1]
-        ctx16 = be.act_cast(ctx.to(device=dev, dtype=torch.float32).reshape(B * Lctx, -1).contiguous(), 0, dt)
-        kv_all = self._linear(ctx16, P["kv_all"], B * Lctx, out_dtype=dt)
+        nctx = ctx.shape[0]
+        assert nctx == (B * F if ctx_per_frame else B), (tuple(ctx.shape), B, F, ctx_per_frame)
+        ctx16 = be.act_cast(ctx.to(device=dev, dtype=torch.float32).reshape(nctx * Lctx, -1).contiguous(), 0, dt)
+        kv_all = self._linear(ctx16, P["kv_all"], nctx * Lctx, out_dtype=dt)
 
         # input conv: im2col of the [B,C,F,H,W] latent straight into rows
         if C % 64 == 0:
@@ -588,7 +594,7 @@ class UNetSD_T2VBase(nn.Module):
                 return self._resblock(mod, h, x2, emb_all, B, F, H, W), H, W
             assert x2 is None
             if isinstance(mod, _SpatialTransformerP):
-                return self._spatial_tx(mod, h, kv_all, B, F, H, W, Lctx), H, W
+                return self._spatial_tx(mod, h, kv_all, B, F, H, W, Lctx, ctx_per_frame), H, W
             if isinstance(mod, _TemporalTransformerP):
                 return self._temporal_tx(mod, h, B, F, H, W), H, W
             if isinstance(mod, _DownP):

@@ -9,8 +9,9 @@ The forward is then the t2v trunk behind a stem conv with `in_dim + concat_dim` 
 last `concat_dim` see zeros.  The spatial compositions (depthmap / motion / canny / mask / sketch / single_sketch /
 local_image, :294-372, 598-699) each add a `concat_dim`-channel map into that buffer; their stems depend only on
 the conditioning maps, so they are evaluated once per conditioning tensor with torch modules and cached (prompt
-constants ahead of the hot path, like UNetSD_I2VGen's).  'histogram' adds a different context token per FRAME,
-which does not fit the per-prompt K/V layout of the native trunk: NotImplementedError.  `UNetSD_TFT2V` (unet_tf2tv.py) is the same class without the unused t_w argument.
+constants ahead of the hot path, like UNetSD_I2VGen's).  'histogram' adds a different context token per FRAME
+(:375-380, 747-755): the trunk then projects K/V per (prompt, frame) — 16 x 78 rows instead of 77 — and the
+cross-attention kernel addresses them frame-major through its strides.  `UNetSD_TFT2V` (unet_tf2tv.py) is the same class without the unused t_w argument.
 The LCM sampler passes float timesteps (inference_videolcm_entrance.py:239); `vgen_timestep_embedding` takes
 fp32 t, so those work unchanged.
 """
@@ -36,8 +37,8 @@ _SPATIAL = {
     "single_sketch": ("single_sketch", "single_sketch_embedding", "single_sketch_embedding_after", 1),
     "local_image": ("local_image", "local_image_embedding", "local_image_embedding_after", 3),
 }
-_UNSUPPORTED = ("histogram",)
-_SUPPORTED_COMPOSITIONS = ("text", "image") + tuple(_SPATIAL)
+_UNSUPPORTED = ()
+_SUPPORTED_COMPOSITIONS = ("text", "image", "histogram") + tuple(_SPATIAL)
 
 
 def _compositions(config):
@@ -56,8 +57,10 @@ class _ComposerTrunk(UNetSD_T2VBase):
     def _extra_stem_channels(kwargs):
         return kwargs["_composer_concat"]
 
-    def _init_composer(self, config, concat_dim, num_tokens, black_image_feature, inpainting, adapter_layers):
+    def _init_composer(self, config, concat_dim, num_tokens, black_image_feature, inpainting, adapter_layers,
+                       hist_dim=156):
         self.cfg = config
+        self.hist_dim = hist_dim
         self.concat_dim = concat_dim
         self.num_tokens = num_tokens
         self.video_compositions = _compositions(config)
@@ -85,6 +88,10 @@ class _ComposerTrunk(UNetSD_T2VBase):
                     nn.Conv2d(c4, c4, 3, stride=2, padding=1), nn.SiLU(), nn.Conv2d(c4, concat_dim, 3, stride=2, padding=1)))
             setattr(self, after, _FrameTransformer(heads=2, dim=concat_dim, dim_head=concat_dim, mlp_dim=concat_dim,
                                                    depth=adapter_layers))
+        if "histogram" in self.video_compositions:
+            # one extra context token PER FRAME (:375-380, 748-755): Linear - SiLU - Linear on [B, F, hist_dim]
+            self.hist_context_embedding = nn.Sequential(nn.Linear(self.hist_dim, self.embed_dim), nn.SiLU(),
+                                                        nn.Linear(self.embed_dim, self.context_dim))
         self._zeros = None
         self._pic = None
         self._stem_cache = {}
@@ -136,10 +143,7 @@ class _ComposerTrunk(UNetSD_T2VBase):
     @torch.no_grad()
     def forward(self, x, t, t_w=None, y=None, image=None, fps=None, video_mask=None, focus_present_mask=None,
                 prob_focus_present=0., mask_last_frame_num=0, **conds):
-        given = [k for k in _UNSUPPORTED if conds.get(k) is not None]
-        if given:
-            raise NotImplementedError(f"{type(self).__name__}: conditions {given}: a per-frame context token does not "
-                                      "fit the per-prompt K/V layout of the native trunk (SURVEY §8 f2)")
+        histogram = conds.pop("histogram", None)
         if self._packed is None:
             self.pack()
         B, C, F, H, W = x.shape
@@ -152,8 +156,7 @@ class _ComposerTrunk(UNetSD_T2VBase):
                 raise ValueError(f"condition '{kwarg}' given but '{name}' is not in video_compositions")
             c = self._spatial_stem(name, cond, B)
             concat = c if concat is None else concat + c
-        unknown = [k for k, v in conds.items() if v is not None and k not in [a[0] for a in _SPATIAL.values()]
-                   and k not in _UNSUPPORTED]
+        unknown = [k for k, v in conds.items() if v is not None and k not in [a[0] for a in _SPATIAL.values()]]
         if unknown:
             raise TypeError(f"{type(self).__name__}.forward: unexpected arguments {unknown}")
         if concat is None:
@@ -166,7 +169,22 @@ class _ComposerTrunk(UNetSD_T2VBase):
             if "image" not in self.video_compositions:
                 raise ValueError("image condition given but 'image' is not in video_compositions")
             ctx = torch.cat([ctx.float(), self._image_tokens(image, B).to(ctx.device)], 1)
-        return self._trunk(torch.cat([x.float(), concat.to(x.device)], 1), t, ctx, fps)
+        per_frame = False
+        if histogram is not None:
+            if "histogram" not in self.video_compositions:
+                raise ValueError("histogram condition given but 'histogram' is not in video_compositions")
+            key = ("histogram", id(histogram), histogram._version)
+            hit = self._stem_cache.get(key)
+            if hit is not None and hit[0] is histogram:
+                hc = hit[1]
+            else:
+                hc = self.hist_context_embedding(histogram.float()).view(B, F, 1, self.context_dim)
+                self._stem_cache[key] = (histogram, hc)
+            # the shared tokens repeated per frame, then this frame's histogram token (:747-755)
+            ctx = torch.cat([ctx.float().unsqueeze(1).expand(B, F, ctx.shape[1], ctx.shape[2]), hc.to(ctx.device)], 2)
+            ctx = ctx.reshape(B * F, ctx.shape[2], ctx.shape[3])
+            per_frame = True
+        return self._trunk(torch.cat([x.float(), concat.to(x.device)], 1), t, ctx, fps, ctx_per_frame=per_frame)
 
     def forward_units(self, x, t, kwargs_list):
         G = len(kwargs_list)
@@ -203,7 +221,8 @@ class UNetSD_VideoLCM(_ComposerTrunk):
                  use_lcm=True, compute_dtype=None, **kwargs):
         self._check(config, "UNetSD_VideoLCM")
         super().__init__(**_trunk_kwargs(locals()), _composer_concat=concat_dim, **kwargs)
-        self._init_composer(config, concat_dim, num_tokens, black_image_feature, inpainting, adapter_transformer_layers)
+        self._init_composer(config, concat_dim, num_tokens, black_image_feature, inpainting, adapter_transformer_layers,
+                            hist_dim)
 
 
 class UNetSD_TFT2V(_ComposerTrunk):
@@ -219,4 +238,5 @@ class UNetSD_TFT2V(_ComposerTrunk):
                  compute_dtype=None, **kwargs):
         self._check(config, "UNetSD_TFT2V")
         super().__init__(**_trunk_kwargs(locals()), _composer_concat=concat_dim, **kwargs)
-        self._init_composer(config, concat_dim, num_tokens, black_image_feature, inpainting, adapter_transformer_layers)
+        self._init_composer(config, concat_dim, num_tokens, black_image_feature, inpainting, adapter_transformer_layers,
+                            hist_dim)
