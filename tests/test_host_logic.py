@@ -271,6 +271,14 @@ def test_vcomposer_spatial_stems_oracle_and_host_logic_vs_reference_golden(emu_b
     n = len(m._stem_cache)
     m(g["x"] * 0.9, g["t"], y=g["y"], image=g["image"], **conds)          # next denoise step: stems come from the cache
     assert len(m._stem_cache) == n == 6
+    # CFG pair in one batch: conditional branch with all maps, "unconditional" with other text and a scaled depth map
+    kw1 = dict(y=g["y"], image=g["image"], **conds)
+    kw2 = dict(kw1, y=torch.roll(g["y"], 1, 1), depth=conds["depth"] * 0.5)
+    a, b = m.forward_units(g["x"], g["t"], [kw1, kw2])
+    # batched vs one-at-a-time: a different GEMM M changes the fp32 summation order, which 16-bit activations
+    # amplify up to their rounding-noise floor (see test_unet_forward_units_matches_sequential on the GPU)
+    assert rel_l2(a, out) < 3e-3 and rel_l2(b, m(g["x"], g["t"], **kw2)) < 3e-3
+    assert abs(rel_l2(a, g["out"]) - rel_l2(out, g["out"])) < 5e-4
     with pytest.raises(ValueError):
         m(g["x"], g["t"], y=g["y"], histogram=torch.zeros(1, 3, 156))  # not in this model's compositions
     with pytest.raises(ValueError):
@@ -294,3 +302,8 @@ def test_histogram_per_frame_context_oracle_and_host_logic_vs_reference_golden(e
     m.load_state_dict(sd, strict=True)
     out = m(g["x"], g["t"], y=g["y"], histogram=g["histogram"], canny=canny)
     assert out.shape == g["out"].shape and rel_l2(out, g["out"]) < 3e-3
+    kw1 = dict(y=g["y"], histogram=g["histogram"], canny=canny)
+    kw2 = dict(y=torch.roll(g["y"], 1, 1), histogram=g["histogram"] * 0.5, canny=canny)
+    a, b = m.forward_units(g["x"], g["t"], [kw1, kw2])       # per-frame contexts of two units stacked frame-major
+    assert rel_l2(a, out) < 3e-3 and rel_l2(b, m(g["x"], g["t"], **kw2)) < 3e-3
+    assert abs(rel_l2(a, g["out"]) - rel_l2(out, g["out"])) < 5e-4

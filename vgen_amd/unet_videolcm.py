@@ -141,12 +141,14 @@ class _ComposerTrunk(UNetSD_T2VBase):
         return out
 
     @torch.no_grad()
-    def forward(self, x, t, t_w=None, y=None, image=None, fps=None, video_mask=None, focus_present_mask=None,
-                prob_focus_present=0., mask_last_frame_num=0, **conds):
+    def _prepare(self, shape, device, y=None, image=None, t_w=None, fps=None, video_mask=None, focus_present_mask=None,
+                 prob_focus_present=0., mask_last_frame_num=0, **conds):
+        """Everything ahead of the trunk for one set of conditions -> (concat [B, concat_dim, F, H, W],
+        ctx [B or B*F, L, D], ctx_per_frame)."""
+        B, C, F, H, W = shape
         histogram = conds.pop("histogram", None)
         if self._packed is None:
             self.pack()
-        B, C, F, H, W = x.shape
         concat = None
         for name, (kwarg, stem, after, cin) in _SPATIAL.items():        # the reference's order of accumulation
             cond = conds.get(kwarg)
@@ -160,15 +162,16 @@ class _ComposerTrunk(UNetSD_T2VBase):
         if unknown:
             raise TypeError(f"{type(self).__name__}.forward: unexpected arguments {unknown}")
         if concat is None:
-            shape = (B, self.concat_dim, F, H, W)
-            if self._zeros is None or self._zeros.shape != shape or self._zeros.device != x.device:
-                self._zeros = torch.zeros(shape, dtype=torch.float32, device=x.device)
+            zshape = (B, self.concat_dim, F, H, W)
+            if self._zeros is None or self._zeros.shape != zshape or self._zeros.device != device:
+                self._zeros = torch.zeros(zshape, dtype=torch.float32, device=device)
             concat = self._zeros
         ctx = y if y is not None else self.zero_y.repeat(B, 1, 1)          # full zero_y here (:740)
+        ctx = ctx.float()
         if image is not None:
             if "image" not in self.video_compositions:
                 raise ValueError("image condition given but 'image' is not in video_compositions")
-            ctx = torch.cat([ctx.float(), self._image_tokens(image, B).to(ctx.device)], 1)
+            ctx = torch.cat([ctx, self._image_tokens(image, B).to(ctx.device)], 1)
         per_frame = False
         if histogram is not None:
             if "histogram" not in self.video_compositions:
@@ -181,25 +184,33 @@ class _ComposerTrunk(UNetSD_T2VBase):
                 hc = self.hist_context_embedding(histogram.float()).view(B, F, 1, self.context_dim)
                 self._stem_cache[key] = (histogram, hc)
             # the shared tokens repeated per frame, then this frame's histogram token (:747-755)
-            ctx = torch.cat([ctx.float().unsqueeze(1).expand(B, F, ctx.shape[1], ctx.shape[2]), hc.to(ctx.device)], 2)
+            ctx = torch.cat([ctx.unsqueeze(1).expand(B, F, ctx.shape[1], ctx.shape[2]), hc.to(ctx.device)], 2)
             ctx = ctx.reshape(B * F, ctx.shape[2], ctx.shape[3])
             per_frame = True
-        return self._trunk(torch.cat([x.float(), concat.to(x.device)], 1), t, ctx, fps, ctx_per_frame=per_frame)
+        return concat.to(device), ctx, per_frame
+
+    @torch.no_grad()
+    def forward(self, x, t, **kw):
+        concat, ctx, per_frame = self._prepare(tuple(x.shape), x.device, **kw)
+        return self._trunk(torch.cat([x.float(), concat], 1), t, ctx, kw.get("fps"), ctx_per_frame=per_frame)
 
     def forward_units(self, x, t, kwargs_list):
+        """CFG pair as one batch of units (see UNetSD_T2VBase.forward_units): stems / context are prepared per
+        unit on the caller's own conditioning tensors (cached), then stacked along the batch."""
         G = len(kwargs_list)
-        ok = ("y", "fps", "t_w", "image")
-        if any(kw.get("y") is None for kw in kwargs_list) or any(k not in ok for kw in kwargs_list for k in kw) or \
-                len({kw.get("image") is None for kw in kwargs_list}) != 1:
+        prep = [self._prepare(tuple(x.shape), x.device, **kw) for kw in kwargs_list]
+        same = len({(p[1].shape[1], p[2]) for p in prep}) == 1 and \
+            len({kw.get("fps") is None for kw in kwargs_list}) == 1
+        if not same:
             return tuple(self.forward(x, t, **kw) for kw in kwargs_list)
-        y = torch.cat([kw["y"] for kw in kwargs_list], 0)
-        image = None
-        if kwargs_list[0].get("image") is not None:
-            image = torch.cat([kw["image"].reshape(x.shape[0], -1) for kw in kwargs_list], 0)
+        B, F = x.shape[0], x.shape[2]
+        concat = torch.cat([p[0] for p in prep], 0)
+        ctx = torch.cat([p[1] for p in prep], 0)             # per-frame contexts are frame-major per prompt: cat is right
         fps = None
-        if all(kw.get("fps") is not None for kw in kwargs_list):
+        if kwargs_list[0].get("fps") is not None:
             fps = torch.cat([kw["fps"].reshape(-1) for kw in kwargs_list], 0)
-        out = self.forward(x.repeat(G, 1, 1, 1, 1), t.repeat(G), y=y, image=image, fps=fps)
+        out = self._trunk(torch.cat([x.float().repeat(G, 1, 1, 1, 1), concat], 1), t.repeat(G), ctx, fps,
+                          ctx_per_frame=prep[0][2])
         return tuple(out.chunk(G, 0))
 
 
