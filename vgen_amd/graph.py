@@ -33,6 +33,8 @@ class GraphedForward:
             if e["calls"] < self.warmup:
                 e["calls"] += 1
                 return self.model(x, t, y=y)
+            if e.get("eager"):
+                return self.model(x, t, y=y)
             e["x"], e["t"], e["y"] = x.clone(), t.clone(), y.clone()
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
@@ -41,8 +43,16 @@ class GraphedForward:
             torch.cuda.current_stream().wait_stream(s)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                e["out"] = self.model(e["x"], e["t"], y=e["y"])
+            try:
+                # thread_local: an RCCL watchdog thread of the process group may touch the runtime while we capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    e["out"] = self.model(e["x"], e["t"], y=e["y"])
+            except Exception as ex:      # noqa: BLE001 — capture is an optimisation: stay correct, say so once
+                import warnings
+                warnings.warn(f"GraphedForward: capture failed ({type(ex).__name__}: {ex}); running eagerly")
+                torch.cuda.synchronize()
+                e["eager"] = True
+                return self.model(x, t, y=y)
             e["graph"] = g
         e["x"].copy_(x)
         e["t"].copy_(t)
