@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VGEN_ABI_VERSION 1
+#define VGEN_ABI_VERSION 2
 
 enum { VGEN_BF16 = 0, VGEN_F16 = 1, VGEN_F32 = 2 };
 
@@ -220,9 +220,17 @@ int vgen_softmax_rows(const float* S, int64_t rows, int32_t cols, int64_t lds, f
 int vgen_act_cast(const float* x, void* y, int64_t n, int32_t act, int32_t dtype, void* stream);
 
 /* sinusoidal_embedding (util.py:178-190): out[b, :] = [cos(t_b * w_i) | sin(t_b * w_i)],
- * w_i = 10000^(-i/half), 16-bit out.  t is fp32 [B]. */
+ * w_i = 10000^(-i/half); out is `dtype` (VGEN_BF16 | VGEN_F16 | VGEN_F32).  t is fp32 [B]. */
 int vgen_timestep_embedding(const float* t, int32_t B, int32_t dim, void* out, int32_t dtype,
                             void* stream);
+
+/* Small-batch fp32 linear, out[r, j] = bias[j] + sum_k act(x[r, k]) * W[j, k] (+ add[r, j]); act_in: 0 =
+ * identity, 1 = SiLU applied to x.  x [n, K], W [N, K], out / add [n, N], all fp32 contiguous, K % 4 == 0.
+ * The time / fps embedding MLPs (unet_t2v.py:93-101, 244-245) and the ResBlocks' emb_layers (util.py:862-868,
+ * all 22 as one [sum(Cout), 1280] matrix): B rows per step, or every timestep once for a session's table.  The
+ * summation order of an output element is independent of n. */
+int vgen_linear_f32(const float* x, int32_t n, int32_t K, const float* W, const float* bias, int32_t N,
+                    int32_t act_in, const float* add, float* out, void* stream);
 
 /* im2col of a small-channel 3x3/pad-1/stride-1 conv into a [M, Kpad] 16-bit matrix
  * (Kpad % 64 == 0, columns (ky*3+kx)*Cin + c, zero padded), so that the 4->320 input conv
@@ -257,6 +265,21 @@ int vgen_pointwise_small(const float* src, int64_t nimg, int32_t Fi, int32_t Cin
 int vgen_cfg_ddim_step(const float* xt, const float* y, const float* u, const float* noise,
                        const float* coef, float guide, int32_t use_guide, int32_t mean_type,
                        int64_t B, int64_t per_b, float* xt_1, float* x0_out, void* stream);
+
+/* The same update addressed for a sampling session (vgen_amd/session.py) whose denoise step is ONE hipGraph:
+ *   xt      : batch element b at xt + b*xt_bstride (per_b contiguous floats) — e.g. the latent channels of
+ *             unit slot b inside the UNet's stacked input [units, C_stem, F, H, W];
+ *   t_idx   : optional int64[B]; coefficient row of b is coef[t_idx[b]*7 ..] (a table over all timesteps, so
+ *             the captured graph needs no per-step host work) instead of coef[b*7 ..];
+ *   xt_1 / x0_out : optional contiguous [B, per_b] outputs;
+ *   rep     : optional; x_{t-1} of b is also written at rep + g*rep_gstride + b*rep_bstride for g < nrep —
+ *             the cond / uncond unit slots of the NEXT step's UNet batch (may alias xt).
+ * Same arithmetic, same order. */
+int vgen_cfg_ddim_step_units(const float* xt, int64_t xt_bstride, const float* y, const float* u,
+                             const float* noise, const float* coef, const int64_t* t_idx, float guide,
+                             int32_t use_guide, int32_t mean_type, int64_t B, int64_t per_b, float* xt_1,
+                             float* x0_out, float* rep, int32_t nrep, int64_t rep_gstride,
+                             int64_t rep_bstride, void* stream);
 
 /* DiagonalGaussianDistribution.sample() * scale (autoencoder.py:212-225, 19-27):
  * moments rows [P, 2*zc] fp32 (mean | logvar), logvar clamped to [-30, 20],

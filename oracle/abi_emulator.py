@@ -155,6 +155,18 @@ class EmuBackend:
     def act_cast(self, x, act, dt):
         return (x * torch.sigmoid(x) if act == 1 else x).to(dt)
 
+    def linear_f32(self, x, W, b, act_in=0, add=None):
+        # float64 accumulation, rounded once: the result of a row does not depend on how many rows are evaluated
+        # together (the kernel's fixed per-element summation order has the same property)
+        v = x.double()
+        if act_in == 1:
+            v = v * torch.sigmoid(v)
+        o = v.float().double() @ W.double().t()
+        if b is not None:
+            o = o + b.double()
+        o = o.float()
+        return o if add is None else o + add
+
     def timestep_embedding(self, t, dim, dt):
         half = dim // 2
         w = torch.pow(torch.tensor(10000.0), -(torch.arange(half).float() / half))
@@ -198,6 +210,21 @@ class EmuBackend:
         if noise is not None:
             r = r + c[6] * c[5] * noise
         return r, (x0.clone() if want_x0 else None)
+
+    def ddim_update_units(self, x_units, G, B, C_lat, y, u, noise, coef_tab, t_idx, guide, use_guide, mean_type,
+                          xt_1, x0, replicate=True):
+        xt = x_units[:B, :C_lat].clone()
+        coef = coef_tab.view(-1, 7)[t_idx] if t_idx is not None else coef_tab.view(-1, 7)[:B]
+        r, x0v = self.cfg_ddim_step(xt, y.view_as(xt), None if u is None else u.view_as(xt),
+                                    None if noise is None else noise.view_as(xt), coef.contiguous(), guide, use_guide,
+                                    mean_type, True)
+        if xt_1 is not None:
+            xt_1.view_as(xt).copy_(r)
+        if x0 is not None:
+            x0.view_as(xt).copy_(x0v)
+        if replicate:
+            x_units.view(G, B, *x_units.shape[1:])[:, :, :C_lat] = r
+        return xt_1, x0
 
     def lowfreq_filter(self, x, nimg, H, W, scale):
         # header formula, evaluated directly (independent of torch.fft)

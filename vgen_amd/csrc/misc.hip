@@ -15,10 +15,17 @@ __global__ __launch_bounds__(256) void act_cast_kernel(const float* __restrict__
   y[i] = T::from_f32(v);
 }
 
+struct F32Out {   // fp32 "storage type" for the kernels that can also emit unrounded values
+  typedef float store_t;
+  static __device__ __forceinline__ float from_f32(float f) { return f; }
+};
+template <typename T> struct StoreOf { typedef uint16_t type; };
+template <> struct StoreOf<F32Out> { typedef float type; };
+
 template <typename T>
 __global__ __launch_bounds__(256) void timestep_embedding_kernel(const float* __restrict__ t, int B,
                                                                  int dim,
-                                                                 uint16_t* __restrict__ out) {
+                                                                 typename StoreOf<T>::type* __restrict__ out) {
   const int half = dim / 2;
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= B * half) return;
@@ -29,6 +36,58 @@ __global__ __launch_bounds__(256) void timestep_embedding_kernel(const float* __
   out[(int64_t)b * dim + k] = T::from_f32(cosf(arg));
   out[(int64_t)b * dim + half + k] = T::from_f32(sinf(arg));
   if ((dim & 1) && k == 0) out[(int64_t)b * dim + dim - 1] = T::from_f32(0.f);
+}
+
+// Small-batch fp32 linear: out[r, j] = bias[j] + sum_k act(x[r, k]) * W[j, k] (+ add[r, j]).  The time / fps
+// embedding MLPs and the ResBlocks' emb_layers see B rows per step (or n_timesteps rows once, when a session
+// folds them into a table): 16-bit MFMA operands buy nothing there.  One wave per output column and 8-row chunk;
+// the chunk of x sits in LDS, every lane owns the k-slices {4*lane + 256*i}, the wave folds by butterfly — the
+// summation order of an output element does not depend on the number of rows, so a table row and a per-step
+// evaluation of the same timestep are bit-identical.
+constexpr int LIN_R = 8;
+__global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict__ x, int n, int K,
+                                                         const float* __restrict__ W,
+                                                         const float* __restrict__ bias, int N, int act_in,
+                                                         const float* __restrict__ add,
+                                                         float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float lin_xs[];   // [LIN_R][K]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r0 = blockIdx.y * LIN_R;
+  const int nr = min(LIN_R, n - r0);
+  for (int i = tid; i < LIN_R * K; i += 256) {
+    const int r = i / K, k = i - r * K;
+    float v = 0.f;
+    if (r < nr) {
+      v = x[(int64_t)(r0 + r) * K + k];
+      if (act_in == 1) v = v / (1.0f + expf(-v));
+    }
+    lin_xs[i] = v;
+  }
+  __syncthreads();
+  const int j = blockIdx.x * 4 + wave;
+  if (j >= N) return;
+  float acc[LIN_R];
+#pragma unroll
+  for (int r = 0; r < LIN_R; ++r) acc[r] = 0.f;
+  const float* wr = W + (int64_t)j * K;
+  for (int k = lane * 4; k < K; k += 256) {
+    const f32x4 w = *(const f32x4*)(wr + k);
+#pragma unroll
+    for (int r = 0; r < LIN_R; ++r) {
+      const f32x4 v = *(const f32x4*)(lin_xs + r * K + k);
+      acc[r] += (v.x * w.x + v.y * w.y) + (v.z * w.z + v.w * w.w);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < LIN_R; ++r) acc[r] = wave_sum(acc[r]);
+  if (lane == 0) {
+    const float b = bias ? bias[j] : 0.f;
+    for (int r = 0; r < nr; ++r) {
+      float v = acc[r] + b;
+      if (add) v += add[(int64_t)(r0 + r) * N + j];
+      out[(int64_t)(r0 + r) * N + j] = v;
+    }
+  }
 }
 
 struct SrcGeom {
@@ -95,16 +154,29 @@ __global__ __launch_bounds__(256) void pointwise_small_kernel(const float* __res
 // CFG combine + DDIM update; arithmetic order mirrors diffusion_ddim.py:157-162,194-197,230-240.
 // FMA contraction is disabled so every product / sum is rounded to fp32 exactly like the
 // reference's separate torch elementwise kernels.
+// Addressing (vgen_cfg_ddim_step_units): batch element b of xt starts at xt + b * xt_bs, its coefficient row
+// is coef[(t_idx ? t_idx[b] : b) * 7 ..], and besides the contiguous xt_1 / x0 outputs the new latent is
+// written `nrep` more times at rep + g * rep_gs + b * rep_bs (the unit slots of the next UNet batch).  A
+// replica may alias xt itself: every thread reads its xt element before it writes anything.
+struct DdimAddr {
+  int64_t per_b, total, xt_bs;
+  const int64_t* t_idx;
+  float* rep;
+  int nrep;
+  int64_t rep_gs, rep_bs;
+};
+
 __global__ __launch_bounds__(256) void cfg_ddim_step_kernel(
-    const float* __restrict__ xt, const float* __restrict__ y, const float* __restrict__ u,
+    const float* xt, const float* __restrict__ y, const float* __restrict__ u,
     const float* __restrict__ noise, const float* __restrict__ coef, float guide, int use_guide,
-    int mean_type, int64_t per_b, int64_t total, float* __restrict__ xt_1,
-    float* __restrict__ x0_out) {
+    int mean_type, const DdimAddr a, float* xt_1, float* x0_out) {
 #pragma clang fp contract(off)
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= total) return;
-  const float* cf = coef + (i / per_b) * 7;
-  const float x = xt[i];
+  if (i >= a.total) return;
+  const int64_t b = i / a.per_b;
+  const int64_t j = i - b * a.per_b;
+  const float* cf = coef + (a.t_idx ? a.t_idx[b] : b) * 7;
+  const float x = xt[b * a.xt_bs + j];
   float out = y[i];
   if (use_guide) {
     const float uu = u[i];
@@ -135,8 +207,9 @@ __global__ __launch_bounds__(256) void cfg_ddim_step_kernel(
     const float nz = ms * noise[i];
     r = r + nz;
   }
-  xt_1[i] = r;
+  if (xt_1) xt_1[i] = r;
   if (x0_out) x0_out[i] = x0;
+  for (int g = 0; g < a.nrep; ++g) a.rep[g * a.rep_gs + b * a.rep_bs + j] = r;
 }
 
 __global__ __launch_bounds__(256) void gaussian_sample_kernel(const float* __restrict__ moments,
@@ -180,17 +253,43 @@ extern "C" int vgen_act_cast(const float* x, void* y, int64_t n, int32_t act, in
 
 extern "C" int vgen_timestep_embedding(const float* t, int32_t B, int32_t dim, void* out,
                                        int32_t dtype, void* stream) {
-  VGEN_REQUIRE(dtype == VGEN_BF16 || dtype == VGEN_F16, "timestep_embedding: dtype");
+  VGEN_REQUIRE(dtype == VGEN_BF16 || dtype == VGEN_F16 || dtype == VGEN_F32, "timestep_embedding: dtype");
   VGEN_REQUIRE(B > 0 && dim >= 2, "timestep_embedding: sizes");
   const int n = B * (dim / 2);
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == VGEN_BF16)
+  if (dtype == VGEN_F32)
+    hipLaunchKernelGGL(timestep_embedding_kernel<F32Out>, dim3((n + 255) / 256), dim3(256), 0, s, t,
+                       B, dim, (float*)out);
+  else if (dtype == VGEN_BF16)
     hipLaunchKernelGGL(timestep_embedding_kernel<BF16>, dim3((n + 255) / 256), dim3(256), 0, s, t,
                        B, dim, (uint16_t*)out);
   else
     hipLaunchKernelGGL(timestep_embedding_kernel<F16>, dim3((n + 255) / 256), dim3(256), 0, s, t,
                        B, dim, (uint16_t*)out);
   return vgen_check_launch("timestep_embedding");
+}
+
+extern "C" int vgen_linear_f32(const float* x, int32_t n, int32_t K, const float* W, const float* bias,
+                               int32_t N, int32_t act_in, const float* add, float* out, void* stream) {
+  VGEN_REQUIRE(n > 0 && N > 0 && K > 0 && K % 4 == 0 && K <= 4096, "linear_f32: n=%d N=%d K=%d (K %% 4, <= 4096)", n, N, K);
+  VGEN_REQUIRE(act_in == 0 || act_in == 1, "linear_f32: act_in");
+  VGEN_REQUIRE(vgen_aligned16(x) && vgen_aligned16(W) && x && W && out, "linear_f32: pointers");
+  const size_t lds = (size_t)LIN_R * K * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)linear_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       LIN_R * 4096 * 4);
+    if (e != hipSuccess) {
+      vgen_set_error("linear_f32: hipFuncSetAttribute failed: %s", hipGetErrorString(e));
+      return (int)e;
+    }
+    attr_done = true;
+  }
+  const dim3 grid((unsigned)((N + 3) / 4), (unsigned)((n + LIN_R - 1) / LIN_R));
+  VGEN_REQUIRE(grid.y <= 65535, "linear_f32: too many rows");
+  hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, n, K, W, bias, N, act_in,
+                     add, out);
+  return vgen_check_launch("linear_f32");
 }
 
 extern "C" int vgen_im2col3x3_small(const float* src, int64_t nimg, int32_t Fi, int32_t Cin,
@@ -234,19 +333,33 @@ extern "C" int vgen_pointwise_small(const float* src, int64_t nimg, int32_t Fi, 
   return vgen_check_launch("pointwise_small");
 }
 
-extern "C" int vgen_cfg_ddim_step(const float* xt, const float* y, const float* u,
-                                  const float* noise, const float* coef, float guide,
-                                  int32_t use_guide, int32_t mean_type, int64_t B, int64_t per_b,
-                                  float* xt_1, float* x0_out, void* stream) {
+extern "C" int vgen_cfg_ddim_step_units(const float* xt, int64_t xt_bstride, const float* y, const float* u,
+                                        const float* noise, const float* coef, const int64_t* t_idx,
+                                        float guide, int32_t use_guide, int32_t mean_type, int64_t B,
+                                        int64_t per_b, float* xt_1, float* x0_out, float* rep, int32_t nrep,
+                                        int64_t rep_gstride, int64_t rep_bstride, void* stream) {
   VGEN_REQUIRE(mean_type >= 0 && mean_type <= 2, "cfg_ddim_step: mean_type");
   VGEN_REQUIRE(!use_guide || u != nullptr, "cfg_ddim_step: guidance needs u");
+  VGEN_REQUIRE(xt != nullptr && y != nullptr && coef != nullptr, "cfg_ddim_step: null xt / y / coef");
+  VGEN_REQUIRE(nrep >= 0 && (nrep == 0 || rep != nullptr), "cfg_ddim_step: replicas");
+  VGEN_REQUIRE(xt_1 != nullptr || nrep > 0, "cfg_ddim_step: no output");
   const int64_t total = B * per_b;
   if (total <= 0) return 0;
   const int64_t grid = (total + 255) / 256;
   VGEN_REQUIRE(grid < (1LL << 31), "cfg_ddim_step: too large");
+  const DdimAddr a{per_b, total, xt_bstride, t_idx, rep, nrep, rep_gstride, rep_bstride};
   hipLaunchKernelGGL(cfg_ddim_step_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream,
-                     xt, y, u, noise, coef, guide, use_guide, mean_type, per_b, total, xt_1, x0_out);
+                     xt, y, u, noise, coef, guide, use_guide, mean_type, a, xt_1, x0_out);
   return vgen_check_launch("cfg_ddim_step");
+}
+
+extern "C" int vgen_cfg_ddim_step(const float* xt, const float* y, const float* u,
+                                  const float* noise, const float* coef, float guide,
+                                  int32_t use_guide, int32_t mean_type, int64_t B, int64_t per_b,
+                                  float* xt_1, float* x0_out, void* stream) {
+  VGEN_REQUIRE(xt_1 != nullptr, "cfg_ddim_step: null output");
+  return vgen_cfg_ddim_step_units(xt, per_b, y, u, noise, coef, nullptr, guide, use_guide, mean_type, B, per_b,
+                                  xt_1, x0_out, nullptr, 0, 0, 0, stream);
 }
 
 extern "C" int vgen_gaussian_sample(const float* moments, const float* noise, int64_t nimg,

@@ -25,6 +25,7 @@ import torch
 
 from . import ops
 from .schedules import beta_schedule
+from .session import SessionCache, eval_units
 
 _MEAN = {"eps": 0, "v": 1, "x0": 2}
 # rows of the per-device fp32 table
@@ -60,7 +61,14 @@ class DiffusionDDIM(object):
         self.posterior_mean_coef1 = betas * torch.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
         self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * torch.sqrt(alphas) / (1.0 - self.alphas_cumprod)
 
+        if var_type not in ("fixed_small", "fixed_large"):
+            # the reference's default 'learned_range' needs a 2*C-channel model output and the VLB terms; no
+            # inference config uses it — say so at construction rather than at the first sampling call
+            raise NotImplementedError(f"DiffusionDDIM(var_type={var_type!r}): learned variances are not on the "
+                                      "sampling path (configs use 'fixed_small'); vgen_amd builds the sampling side only")
         self._tab = {}
+        self._coef_tabs = {}
+        self.sessions = SessionCache()  # per-(model, kwarg sets, shape) sampling sessions (vgen_amd/session.py)
         self.partition = None          # optional vgen_amd.parallel.UnitPartition
         self.rng_parity = True         # draw the (unused when eta == 0) per-step noise like the reference
 
@@ -98,15 +106,11 @@ class DiffusionDDIM(object):
         if guide_scale is None:
             return model(xt, ts, **model_kwargs), None
         assert isinstance(model_kwargs, list) and len(model_kwargs) == 2
-        inner = getattr(model, "module", model)
-        if self.partition is not None:
-            y_out, u_out = self.partition.run_units(inner, xt, ts, model_kwargs)
-        elif hasattr(inner, "forward_units"):
-            y_out, u_out = inner.forward_units(xt, ts, model_kwargs)
-        else:
-            y_out = model(xt, ts, **model_kwargs[0])
-            u_out = model(xt, ts, **model_kwargs[1])
-        return y_out, u_out
+        outs = eval_units(self.sessions, self.partition, model, xt, ts, model_kwargs,
+                          None if self.rescale_timesteps else self.num_timesteps)
+        if outs is not None:
+            return outs
+        return model(xt, ts, **model_kwargs[0]), model(xt, ts, **model_kwargs[1])
 
     def _x0_coefs(self, tab, t):
         if self.mean_type == "v":
@@ -118,32 +122,75 @@ class DiffusionDDIM(object):
             return z, z
         raise NotImplementedError("mean_type 'x_{t-1}' is not on the sampling path")
 
-    def _fused(self, xt, t, model, model_kwargs, guide_scale, alphas_prev, sigmas, mask, noise,
-               clamp, percentile, want_x0=True):
+    def _coef_rows(self, tab, t, kind, stride, eta):
+        """The 7 coefficients of vgen_cfg_ddim_step for timesteps `t` (any shape of long indices), fp32, in the
+        reference's expression order (diffusion_ddim.py:232-234 for 'ddim', :262-270 for 'reverse'; 'x0' is
+        p_mean_variance alone: alpha_prev = 1, sigma = 0)."""
+        a0, a1 = self._x0_coefs(tab, t)
+        alphas = tab[_AC][t]
+        if kind == "ddim":
+            alphas_prev = tab[_AC][(t - stride).clamp(0)]
+            sigmas = eta * torch.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
+            mask = t.ne(0).float()
+        elif kind == "reverse":
+            alphas_prev = tab[_AC_NEXT][(t + stride).clamp(0, self.num_timesteps)]
+            sigmas = torch.zeros_like(alphas_prev)
+            mask = torch.zeros_like(alphas_prev)
+        else:
+            alphas_prev = torch.ones_like(alphas)
+            sigmas = torch.zeros_like(alphas)
+            mask = torch.zeros_like(alphas)
+        return torch.stack([a0, a1, tab[_SQRT_RECIP][t], tab[_SQRT_RECIPM1][t], alphas_prev, sigmas, mask],
+                           dim=-1).contiguous()
+
+    def _coef_table(self, device, kind, stride, eta):
+        """Coefficient rows of ALL integer timesteps ([T, 7]): a sampling session's step graph gathers row t on
+        the device, so a step needs no host-side scalar work."""
+        key = (str(device), kind, int(stride), float(eta))
+        tabc = self._coef_tabs.get(key)
+        if tabc is None:
+            t = torch.arange(self.num_timesteps, dtype=torch.long, device=device)
+            tabc = self._coef_rows(self._table(device), t, kind, stride, eta)
+            self._coef_tabs[key] = tabc
+        return tabc
+
+    def _session(self, xt, t, model, model_kwargs, guide_scale):
+        """The UnitSession for this (model, kwarg sets, latent shape), or None: arbitrary callables, float /
+        rescaled timesteps and partitioned steps take the eager path."""
+        if self.sessions is None or self.partition is not None or self.rescale_timesteps \
+                or t.dtype != torch.long or xt.dim() != 5:
+            return None
+        kws = model_kwargs if guide_scale is not None else [model_kwargs]
+        if not isinstance(kws, (list, tuple)) or len(kws) != (2 if guide_scale is not None else 1):
+            return None
+        if not all(isinstance(kw, dict) for kw in kws):
+            return None
+        return self.sessions.get(model, tuple(xt.shape), xt.device, list(kws), torch.long, self.num_timesteps)
+
+    def _fused(self, xt, t, model, model_kwargs, guide_scale, kind, stride, eta, noise, clamp, percentile,
+               alias_ok=False):
+        """(x_next, x0) = fused CFG + x0 + update of `kind` ('ddim' | 'reverse' | 'x0') after evaluating the model."""
         if clamp is not None or percentile is not None:
             raise NotImplementedError("clamp / percentile are unused by the inference configs")
-        if self.var_type not in ("fixed_small", "fixed_large"):
-            raise NotImplementedError("learned variances are not on the sampling path")
+        sess = self._session(xt, t, model, model_kwargs, guide_scale)
+        if sess is not None:
+            return sess.ddim_step(xt, t, self._coef_table(xt.device, kind, stride, eta),
+                                  0.0 if guide_scale is None else float(guide_scale), _MEAN[self.mean_type],
+                                  noise, clone=not alias_ok)
         y_out, u_out = self._eval_model(xt, t, model, model_kwargs, guide_scale)
-        tab = self._table(xt.device)
-        a0, a1 = self._x0_coefs(tab, t)
-        coef = torch.stack([a0, a1, tab[_SQRT_RECIP][t], tab[_SQRT_RECIPM1][t], alphas_prev, sigmas,
-                            mask], dim=1).contiguous()
+        coef = self._coef_rows(self._table(xt.device), t, kind, stride, eta)
         xt32 = xt.float().contiguous()
         y32 = y_out.float().contiguous()
         u32 = None if u_out is None else u_out.float().contiguous()
         return ops.backend().cfg_ddim_step(xt32, y32, u32, noise, coef,
                                            0.0 if guide_scale is None else float(guide_scale),
-                                           guide_scale is not None, _MEAN[self.mean_type], want_x0)
+                                           guide_scale is not None, _MEAN[self.mean_type], True)
 
     # -- p(x_{t-1} | x_t) pieces used by the samplers ---------------------------------------------
     @torch.no_grad()
     def p_mean_variance(self, xt, t, model, model_kwargs={}, clamp=None, percentile=None, guide_scale=None):
         """Returns (mu, var, log_var, x0) like the reference; x0 comes from the fused kernel."""
-        tab = self._table(xt.device)
-        one = torch.ones_like(tab[_AC][t])
-        _, x0 = self._fused(xt, t, model, model_kwargs, guide_scale, one, torch.zeros_like(one),
-                            torch.zeros_like(one), None, clamp, percentile)
+        _, x0 = self._fused(xt, t, model, model_kwargs, guide_scale, "x0", 0, 0.0, None, clamp, percentile)
         shape = (xt.size(0),) + (1,) * (xt.ndim - 1)
         g = lambda v: v.to(torch.float32).to(xt.device)[t].view(shape)
         if self.var_type == "fixed_large":
@@ -157,24 +204,21 @@ class DiffusionDDIM(object):
 
     @torch.no_grad()
     def ddim_sample(self, xt, t, model, model_kwargs={}, clamp=None, percentile=None, condition_fn=None,
-                    guide_scale=None, ddim_timesteps=20, eta=0.0):
+                    guide_scale=None, ddim_timesteps=20, eta=0.0, _alias_ok=False):
+        """One DDIM step (diffusion_ddim.py:208-241).  For vgen_amd models the whole step — both CFG branches as
+        one UNet batch plus the fused update — is a hipGraph replay of a cached sampling session; any other
+        `model` callable runs eagerly through the same update kernel."""
         if condition_fn is not None:
             raise NotImplementedError("classifier guidance (condition_fn) is unused by the inference configs")
         stride = self.num_timesteps // ddim_timesteps
-        tab = self._table(xt.device)
-        # per-batch scalars, fp32, same expression order as diffusion_ddim.py:232-234
-        alphas = tab[_AC][t]
-        alphas_prev = tab[_AC][(t - stride).clamp(0)]
-        sigmas = eta * torch.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
-        mask = t.ne(0).float()
         noise = None
         if self.rng_parity or eta != 0.0:
             noise = torch.randn_like(xt)             # drawn every step by the reference (:237)
         if eta == 0.0:
             noise = None                             # sigma == 0: the term is exactly +0
-        xt_1, x0 = self._fused(xt, t, model, model_kwargs, guide_scale, alphas_prev, sigmas, mask,
-                               noise if noise is None else noise.float().contiguous(), clamp, percentile)
-        return xt_1, x0
+        return self._fused(xt, t, model, model_kwargs, guide_scale, "ddim", stride, eta,
+                           noise if noise is None else noise.float().contiguous(), clamp, percentile,
+                           alias_ok=_alias_ok)
 
     @torch.no_grad()
     def ddim_sample_loop(self, noise, model, model_kwargs={}, clamp=None, percentile=None,
@@ -185,22 +229,19 @@ class DiffusionDDIM(object):
             .clamp(0, self.num_timesteps - 1).flip(0)
         for step in steps:
             t = torch.full((b,), int(step), dtype=torch.long, device=xt.device)
+            # _alias_ok: inside the loop the session hands back its own x_{t-1} buffer (no copies between steps)
             xt, _ = self.ddim_sample(xt, t, model, model_kwargs, clamp, percentile, condition_fn,
-                                     guide_scale, ddim_timesteps, eta)
-        return xt
+                                     guide_scale, ddim_timesteps, eta, _alias_ok=True)
+        return xt.clone()
 
     @torch.no_grad()
     def ddim_reverse_sample(self, xt, t, model, model_kwargs={}, clamp=None, percentile=None,
-                            guide_scale=None, ddim_timesteps=20):
+                            guide_scale=None, ddim_timesteps=20, _alias_ok=False):
         """x_t -> x_{t+stride} along the deterministic DDIM ODE (diffusion_ddim.py:256-274):
         mu = sqrt(a_next) * x0 + sqrt(1 - a_next) * eps — the same kernel with sigma = 0."""
         stride = self.num_timesteps // ddim_timesteps
-        tab = self._table(xt.device)
-        alphas_next = tab[_AC_NEXT][(t + stride).clamp(0, self.num_timesteps)]
-        zero = torch.zeros_like(alphas_next)
-        mu, x0 = self._fused(xt, t, model, model_kwargs, guide_scale, alphas_next, zero, zero, None,
-                             clamp, percentile)
-        return mu, x0
+        return self._fused(xt, t, model, model_kwargs, guide_scale, "reverse", stride, 0.0, None, clamp, percentile,
+                           alias_ok=_alias_ok)
 
     @torch.no_grad()
     def ddim_reverse_sample_loop(self, x0, model, model_kwargs={}, clamp=None, percentile=None,
@@ -211,5 +252,5 @@ class DiffusionDDIM(object):
         for step in steps:
             t = torch.full((b,), int(step), dtype=torch.long, device=xt.device)
             xt, _ = self.ddim_reverse_sample(xt, t, model, model_kwargs, clamp, percentile, guide_scale,
-                                             ddim_timesteps)
-        return xt
+                                             ddim_timesteps, _alias_ok=True)
+        return xt.clone()

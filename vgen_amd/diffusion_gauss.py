@@ -28,6 +28,7 @@ import torch
 
 from . import ops
 from .schedules import sigma_schedule
+from .session import SessionCache, eval_units
 
 _PRED = {"eps": 0, "v": 1, "x0": 2}
 
@@ -84,6 +85,7 @@ class GaussianDiffusion(object):
         self.num_timesteps = len(sigmas)
         self.prediction_type = prediction_type
         self.partition = None
+        self.sessions = SessionCache()         # cached sampling sessions (vgen_amd/session.py): one replay per step
         self.noise_sampler_cls = None          # default: torchsde tree if importable, else IntervalNoise
 
     # -- q(x_t | x_0) ---------------------------------------------------------------------------------
@@ -99,11 +101,9 @@ class GaussianDiffusion(object):
         assert isinstance(model_kwargs, list) and len(model_kwargs) == 2
         if guide_scale == 1.:
             return model(xt, t=t, **model_kwargs[0]), None
-        inner = getattr(model, "module", model)
-        if self.partition is not None:
-            return self.partition.run_units(inner, xt, t, model_kwargs)
-        if hasattr(inner, "forward_units"):
-            return inner.forward_units(xt, t, model_kwargs)
+        outs = eval_units(self.sessions, self.partition, model, xt, t, model_kwargs, self.num_timesteps)
+        if outs is not None:
+            return outs
         return model(xt, t=t, **model_kwargs[0]), model(xt, t=t, **model_kwargs[1])
 
     def _x0_eps(self, xt, t, model, model_kwargs, guide_scale, guide_rescale, clamp, percentile, want_eps):

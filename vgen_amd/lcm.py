@@ -28,6 +28,7 @@ import numpy as np
 import torch
 
 from . import ops
+from .session import SessionCache, eval_units
 
 
 def _rescale_zero_terminal_snr_f32(betas: torch.Tensor) -> torch.Tensor:
@@ -150,12 +151,16 @@ class LCMScheduler:
         cfg = guidance_scale is not None and len(model_kwargs) > 1 and guidance_scale != 1.0
         coef = torch.ones((B, 2), dtype=torch.float32, device=latents.device)
         self._step_index = None
+        sessions = SessionCache(capacity=1)
         for k, t in enumerate(self.timesteps):
             tt = t.repeat(B).to(device=latents.device, dtype=latents.dtype)
             x_in = self.scale_model_input(latents, t)
-            inner = getattr(model, "module", model)
-            if cfg and hasattr(inner, "forward_units"):
-                y_out, u_out = inner.forward_units(x_in, tt, [dict(model_kwargs[0]), dict(model_kwargs[1])])
+            # the engine's kwarg sets are the same objects on every step: one sampling session per loop, a step
+            # is one model-graph replay (K/V, condition stems computed once; vgen_amd/session.py)
+            outs = eval_units(sessions, None, model, x_in, tt,
+                              [model_kwargs[0], model_kwargs[1]] if cfg else [model_kwargs[0]])
+            if outs is not None:
+                y_out, u_out = (outs[0], outs[1]) if cfg else (outs[0], None)
             else:
                 y_out = model(x_in, tt, t_w=None, **model_kwargs[0])
                 u_out = model(x_in, tt, t_w=None, **model_kwargs[1]) if cfg else None

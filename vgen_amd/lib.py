@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(HERE, "libvgen_hip.so")
 VGEN_BF16, VGEN_F16, VGEN_F32 = 0, 1, 2
 TAP_LINEAR, TAP_CONV3X3, TAP_TEMPORAL3 = 0, 1, 2
 EPI_NONE, EPI_GEGLU = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class VgenHipError(RuntimeError):
@@ -71,11 +71,14 @@ SYMBOLS = {
     "vgen_softmax_rows": (C.c_int, [_vp, _i64, _i32, _i64, _f32, _vp, _i64, _i32, _vp]),
     "vgen_act_cast": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "vgen_timestep_embedding": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp]),
+    "vgen_linear_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "vgen_im2col3x3_small": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64,
                                        _i64, _vp, _i32, _i32, _vp]),
     "vgen_pointwise_small": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64,
                                        _i64, _vp, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _i64,
                                        _vp]),
+    "vgen_cfg_ddim_step_units": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _i64, _i64, _vp,
+                                           _vp, _vp, _i32, _i64, _i64, _vp]),
     "vgen_cfg_ddim_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _f32, _i32, _i32, _i64, _i64, _vp,
                                      _vp, _vp]),
     "vgen_gaussian_sample": (C.c_int, [_vp, _vp, _i64, _i32, _i64, _f32, _vp, _vp]),

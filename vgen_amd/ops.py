@@ -270,6 +270,19 @@ class HipBackend:
         _lib.check(rc, "vgen_act_cast")
         return y
 
+    def linear_f32(self, x, W, b, act_in=0, add=None):
+        """out = act(x) @ W^T + b (+ add), fp32 (vgen_linear_f32)."""
+        for t in (x, W, b, add):
+            assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+        n, K = x.shape
+        N = W.shape[0]
+        assert W.shape[1] == K and (add is None or add.shape == (n, N))
+        out = torch.empty((n, N), dtype=torch.float32, device=x.device)
+        rc = self.lib.vgen_linear_f32(_ptr(x), n, K, _ptr(W), _ptr(b), N, int(act_in), _ptr(add), _ptr(out),
+                                      self._stream(x))
+        _lib.check(rc, "vgen_linear_f32")
+        return out
+
     def timestep_embedding(self, t, dim, dt):
         assert t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 1
         out = torch.empty((t.shape[0], dim), dtype=dt, device=t.device)
@@ -306,6 +319,26 @@ class HipBackend:
                                          _ptr(out), _ptr(x0), self._stream(xt))
         _lib.check(rc, "vgen_cfg_ddim_step")
         return out, x0
+
+    def ddim_update_units(self, x_units, G, B, C_lat, y, u, noise, coef_tab, t_idx, guide, use_guide, mean_type,
+                          xt_1, x0, replicate=True):
+        """vgen_cfg_ddim_step_units on a session's stacked UNet input `x_units` [G*B, C_stem, F, H, W] (unit
+        g*B + b; the latent of batch element b is the first C_lat channels of unit b): reads x_t from unit slot
+        (0, b), the coefficient row coef_tab[t_idx[b]], writes x_{t-1} to `xt_1` (and x0) and, with `replicate`,
+        into the latent channels of all G unit slots — the next step's UNet input."""
+        assert x_units.dtype == torch.float32 and x_units.is_contiguous() and x_units.shape[0] == G * B
+        unit = x_units[0].numel()
+        per_b = C_lat * x_units[0, 0].numel()
+        for t in (y, u, noise, xt_1, x0):
+            assert t is None or (t.dtype == torch.float32 and t.is_contiguous() and t.numel() == B * per_b)
+        assert coef_tab.dtype == torch.float32 and coef_tab.is_contiguous() and coef_tab.shape[-1] == 7
+        assert t_idx is None or (t_idx.dtype == torch.int64 and t_idx.is_contiguous() and t_idx.numel() == B)
+        rc = self.lib.vgen_cfg_ddim_step_units(
+            _ptr(x_units), unit, _ptr(y), _ptr(u), _ptr(noise), _ptr(coef_tab), _ptr(t_idx), float(guide),
+            int(use_guide), int(mean_type), B, per_b, _ptr(xt_1), _ptr(x0),
+            _ptr(x_units) if replicate else None, G if replicate else 0, B * unit, unit, self._stream(x_units))
+        _lib.check(rc, "vgen_cfg_ddim_step_units")
+        return xt_1, x0
 
     def lowfreq_filter(self, x, nimg, H, W, scale):
         assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[0] == nimg * H * W

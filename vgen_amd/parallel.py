@@ -3,14 +3,19 @@
 A denoise step evaluates U = P x G independent UNet forwards ("units": P prompts/seeds in flight,
 G = 2 classifier-free-guidance branches).  Units share nothing but weights, so they shard with no
 data-path collective inside the UNet; the only exchange is ONE all-gather of the unit outputs per
-step (RCCL over xGMI when the process group is `nccl`; 229 KB bf16 / 459 KB fp32 per unit at the
-t2v shape — latency-bound), after which every rank applies the cheap fused CFG + DDIM update
-redundantly for all prompts.  The reference has no such path (every rank re-runs the whole prompt
-list: tools/inferences/inference_text2video_entrance.py:93,165-171); this is the design the
-north-star asks for.
+step (RCCL over xGMI when the process group is `nccl`; 459 KB fp32 per unit at the t2v shape —
+latency-bound, so the payload stays fp32 and exact), after which every rank applies the cheap fused
+CFG + DDIM update redundantly for all prompts.  The reference has no such path (every rank re-runs
+the whole prompt list: tools/inferences/inference_text2video_entrance.py:93,165-171); this is the
+design the north-star asks for.
 
 unit u = p * G + g  ->  rank u % W.  One process per GPU; torch.distributed supplies the
 process group (backend "nccl" == RCCL on ROCm, "gloo" in the CPU tests).
+
+The local units run through a sampling session (vgen_amd/session.py): their condition stems and K/V are
+prompt constants computed once, and the local UNet batch is one hipGraph replay that writes straight into
+this rank's all-gather slot; the gather and the update kernel stay eager between two replays (a collective
+inside a captured graph could not be validated on the 1-GPU development boxes).
 """
 from __future__ import annotations
 
@@ -20,11 +25,24 @@ import torch
 import torch.distributed as dist
 
 
+def _slice_kwargs(kw, ps, P):
+    """kwargs of the prompts `ps`: every tensor batched over the P prompts is indexed, everything else is shared."""
+    out = {}
+    for k, v in kw.items():
+        if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == P:
+            out[k] = v[ps]
+        else:
+            out[k] = v
+    return out
+
+
 class UnitPartition:
     def __init__(self, group=None):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        from .session import SessionCache
+        self.sessions = SessionCache()
 
     # -- static helpers --------------------------------------------------------------------------
     def owner(self, u: int) -> int:
@@ -37,39 +55,59 @@ class UnitPartition:
         return (U + self.world - 1) // self.world
 
     # -- the per-step exchange -----------------------------------------------------------------------
-    def gather_units(self, mine: Sequence[torch.Tensor], U: int, like: torch.Tensor) -> List[torch.Tensor]:
-        """`mine`: outputs of my_units(U) in order, each shaped like `like` (one unit).
-        Returns the U unit outputs on every rank after ONE all-gather."""
+    def gather_stacked(self, mine: torch.Tensor, U: int) -> List[torch.Tensor]:
+        """`mine`: [len(my_units(U)), ...] outputs of this rank's units in order.  Returns the U unit outputs on
+        every rank after ONE all-gather."""
         S = self.slots(U)
-        buf = like.new_zeros((S,) + tuple(like.shape))
-        for i, o in enumerate(mine):
-            buf[i].copy_(o)
         if self.world == 1:
-            return [buf[i] for i in range(U)]
-        allb = like.new_empty((self.world * S,) + tuple(like.shape))
+            return [mine[i] for i in range(U)]
+        if mine.shape[0] == S and mine.is_contiguous():
+            buf = mine
+        else:                                                   # ragged tail: this rank owns fewer than S units
+            buf = mine.new_zeros((S,) + tuple(mine.shape[1:]))
+            buf[: mine.shape[0]].copy_(mine)
+        allb = mine.new_empty((self.world * S,) + tuple(mine.shape[1:]))
         dist.all_gather_into_tensor(allb, buf, group=self.group)
         # unit u sits in rank (u % W)'s slot (u // W)
         return [allb[(u % self.world) * S + (u // self.world)] for u in range(U)]
 
+    def gather_units(self, mine: Sequence[torch.Tensor], U: int, like: torch.Tensor) -> List[torch.Tensor]:
+        """List form of gather_stacked (each element shaped like `like`)."""
+        if len(mine):
+            st = torch.stack(list(mine))
+        else:
+            st = like.new_zeros((0,) + tuple(like.shape))
+        return self.gather_stacked(st, U)
+
     # -- classifier-free guidance for P prompts stacked in the batch dim ---------------------------------
-    def run_units(self, model, xt, t, model_kwargs):
-        """xt [P, C, F, H, W], t [P], model_kwargs = [cond_kwargs, uncond_kwargs] with per-prompt `y`
-        stacked along dim 0.  Returns (y_out, u_out), each [P, ...], identical on every rank."""
+    def run_units(self, model, xt, t, model_kwargs, num_timesteps=None):
+        """xt [P, C, F, H, W], t [P], model_kwargs = list of G kwarg sets whose tensors are stacked over the P
+        prompts along dim 0.  Returns G tensors [P, out_dim, F, H, W], identical on every rank."""
         G = len(model_kwargs)
         P = xt.shape[0]
         U = P * G
         mine = self.my_units(U)
-        outs = []
-        if mine:
-            xs = torch.stack([xt[u // G] for u in mine])
-            ts = torch.stack([t[u // G] for u in mine])
-            ys = torch.stack([model_kwargs[u % G]["y"][u // G] for u in mine])
-            extra = {k: v for k, v in model_kwargs[0].items() if k not in ("y", "fps")}
-            o = model(xs, ts, y=ys, **extra)
-            outs = [o[i] for i in range(len(mine))]
-            like = o[0]
+        out_dim = getattr(model, "out_dim", xt.shape[1])
+        unit_shape = (out_dim,) + tuple(xt.shape[2:])
+        # a vgen_amd model: session over the local units (session index g * P + p); tables only for long t
+        sess = None
+        if xt.dim() == 5 and hasattr(model, "_prepare_units"):
+            nt = num_timesteps if t.dtype == torch.long else None
+            sess = self.sessions.get(model, tuple(xt.shape), xt.device, list(model_kwargs), t.dtype, nt,
+                                     units=[(u % G) * P + (u // G) for u in mine])
+        if sess is not None:
+            local = sess.eval(xt, t)                                       # [len(mine), out_dim, F, H, W]
         else:
-            like = xt.new_zeros((getattr(model, "out_dim", xt.shape[1]),) + tuple(xt.shape[2:]),
-                                dtype=torch.float32)
-        allu = self.gather_units(outs, U, like)
+            outs = {}
+            for g in range(G):
+                ps = [u // G for u in mine if u % G == g]
+                if not ps:
+                    continue
+                idx = torch.tensor(ps, device=xt.device)
+                o = model(xt[idx], t[idx], **_slice_kwargs(model_kwargs[g], idx, P))
+                for i, p in enumerate(ps):
+                    outs[p * G + g] = o[i].float()
+            local = torch.stack([outs[u] for u in mine]) if mine else \
+                xt.new_zeros((0,) + unit_shape, dtype=torch.float32)
+        allu = self.gather_stacked(local, U)
         return tuple(torch.stack([allu[p * G + g] for p in range(P)]) for g in range(G))

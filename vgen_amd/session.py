@@ -1,0 +1,236 @@
+"""Sampling sessions: what stays fixed across the denoise steps of one prompt is computed once, and a step is ONE
+hipGraph replay.
+
+The reference's engines call `diffusion.ddim_sample_loop(noise, model, model_kwargs=[cond, uncond], ...)`
+(tools/inferences/inference_text2video_entrance.py:200-206); every step then re-runs, per CFG branch, the condition
+stems, `to_k / to_v` of the 16 cross-attention blocks on the unchanged context (tools/modules/unet/util.py:233-235,
+after a x16 repeat_interleave, unet_t2v.py:255), the time-embedding MLP (unet_t2v.py:93-96,244-245) and ~12 torch
+elementwise launches of the update (diffusion_ddim.py:157-162,194-197,230-240).  Between two steps only x_t and t
+change.  A `UnitSession` therefore holds, for the G kwarg sets x B latents = G*B "units" of one step:
+
+  x_units  [G*B, C_stem, F, H, W]  the UNet's stacked input; the condition-stem channels are written once, the
+                                   latent channels of every unit slot are (re)written by the update kernel itself
+  kv       K/V rows of all cross-attention blocks for every unit's context (one GEMM, once)
+  t_units  [G*B] the timestep, the only per-step host input (plus optional noise)
+  coefficient / time-embedding TABLES over all integer timesteps, gathered on the device by t
+
+and captures   emb[t] -> UNet body -> fused CFG + DDIM update   as one graph (torch.cuda.graph over the C-ABI
+launches, which only enqueue on the current stream).  Samplers that do their own update (DPM-Solver++, LCM) replay
+the model-only graph and read the unit outputs.  On CPU tensors (the test-suite's ABI emulator) or with
+VGEN_GRAPH=0 the same launch sequence runs eagerly — one code path, captured or not.
+
+Sessions are cached on the diffusion object, keyed on the model (and its weights epoch), the latent shape and the
+IDENTITY + version of every tensor in the kwarg sets (the engines pass the same tensors on every step).
+"""
+from __future__ import annotations
+
+import os
+import warnings
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import ops
+
+_GRAPH_ON = os.environ.get("VGEN_GRAPH", "1") != "0"
+
+
+def _kw_key(kwargs_list):
+    key = []
+    for kw in kwargs_list:
+        items = []
+        for k in sorted(kw):
+            v = kw[k]
+            if torch.is_tensor(v):
+                items.append((k, id(v), v._version, tuple(v.shape), v.dtype))
+            else:
+                items.append((k, repr(v)))
+        key.append(tuple(items))
+    return tuple(key)
+
+
+class UnitSession:
+    def __init__(self, model, shape, device, kwargs_list, t_dtype=torch.long, num_timesteps=None,
+                 units: Optional[Sequence[int]] = None):
+        """`units`: subset of unit indices (g*B + b) evaluated here (vgen_amd.parallel partitions a step's units
+        over the ranks); default all."""
+        self.model = model
+        self.G = len(kwargs_list)
+        self.B, self.C_lat, self.F, self.H, self.W = shape
+        self.device = torch.device(device)
+        self.kwargs_ref = [dict(kw) for kw in kwargs_list]         # keeps the keyed tensors alive (ids stay unique)
+        if model._packed is None:
+            model.pack()
+        prep = model._prepare_units(tuple(shape), self.device, kwargs_list)
+        if prep is None:
+            raise ValueError("kwarg sets cannot share one UNet batch")
+        U = self.G * self.B
+        sel = list(range(U)) if units is None else list(units)
+        self.units = sel
+        self.full = units is None
+        nU = len(sel)
+        idx = torch.tensor(sel, dtype=torch.long, device=self.device)
+        C_stem = model._stem_channels()
+        self.x_units = torch.zeros((nU, C_stem, self.F, self.H, self.W), dtype=torch.float32, device=self.device)
+        if prep["extra"] is not None:
+            assert prep["extra"].shape[1] == C_stem - self.C_lat
+            self.x_units[:, self.C_lat:] = prep["extra"].to(self.device).float()[idx]
+        else:
+            assert C_stem == self.C_lat, (C_stem, self.C_lat)
+        ctx = prep["ctx"].to(self.device)
+        self.per_frame = bool(prep["per_frame"])
+        if self.per_frame:
+            ctx = ctx.view(U, self.F, *ctx.shape[1:])[idx].reshape(nU * self.F, *ctx.shape[1:])
+        else:
+            ctx = ctx[idx]
+        self.Lctx = ctx.shape[1]
+        self.kv = model._context_kv(ctx.contiguous(), self.device) if nU else None   # prompt constant: once
+        self.fps = None if prep["fps"] is None else prep["fps"].to(self.device)[idx].contiguous()
+        self.t_units = torch.zeros((nU,), dtype=t_dtype, device=self.device)
+        self.out = torch.empty((nU, model.out_dim, self.F, self.H, self.W), dtype=torch.float32, device=self.device)
+        # time-embedding table: integer timesteps of a known schedule length, no fps term inside the SiLU
+        self.emb_tab = None
+        if num_timesteps and not t_dtype.is_floating_point and self.fps is None:
+            self.emb_tab = model.time_embedding_table(int(num_timesteps), self.device)
+        self.use_graph = _GRAPH_ON and self.device.type == "cuda"
+        self._graphs = {}
+        self._static = {}
+        self.xt_1 = torch.empty((self.B, self.C_lat, self.F, self.H, self.W), dtype=torch.float32, device=self.device)
+        self.x0 = torch.empty_like(self.xt_1)
+        self._last_out = None       # the tensor handed to the caller by the previous fused step
+
+    # -- inputs --------------------------------------------------------------------------------------
+    def load(self, xt, t):
+        """x_t -> latent channels of every unit slot, t -> t_units (two broadcast copies)."""
+        if len(self.units) == 0:
+            return
+        if self.full:
+            if xt is not self._last_out:       # after a fused step the update kernel already wrote the slots
+                self.x_units.view(self.G, self.B, *self.x_units.shape[1:])[:, :, :self.C_lat].copy_(xt)
+            self.t_units.view(self.G, self.B).copy_(t.to(self.t_units.dtype))
+        else:
+            b = torch.tensor([u % self.B for u in self.units], device=self.device)
+            self.x_units[:, :self.C_lat].copy_(xt.float()[b])
+            self.t_units.copy_(t.to(self.t_units.dtype)[b])
+        self._last_out = None
+
+    # -- launch sequences ----------------------------------------------------------------------------
+    def _model_launches(self):
+        m = self.model
+        nU = len(self.units)
+        if self.emb_tab is not None:
+            emb = self.emb_tab.index_select(0, self.t_units)
+        else:
+            emb = m._embed(self.t_units, self.fps, nU, self.device)
+        m._body(self.x_units, emb, self.kv, self.Lctx, self.per_frame, out=self.out)
+
+    def _run(self, key, launches):
+        """Run `launches()` eagerly (first call: warms the allocator, JIT-free) and from then on as a graph."""
+        if not self.use_graph:
+            launches()
+            return
+        g = self._graphs.get(key)
+        if g is None:
+            st = self._static.setdefault(key, {"calls": 0})
+            st["calls"] += 1
+            if st["calls"] == 1:
+                launches()                      # eager warm-up pass with the caller's inputs
+                return
+            torch.cuda.synchronize(self.device)
+            g = torch.cuda.CUDAGraph()
+            try:
+                # thread_local: a watchdog thread of the process group may touch the runtime while we capture
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    launches()
+            except Exception as ex:             # noqa: BLE001 — capture is an optimisation: stay correct, say so
+                warnings.warn(f"UnitSession: hipGraph capture failed ({type(ex).__name__}: {ex}); running eagerly")
+                torch.cuda.synchronize(self.device)
+                self.use_graph = False
+                launches()
+                return
+            self._graphs[key] = g
+        g.replay()
+
+    # -- model only (samplers with their own update) ----------------------------------------------------
+    def eval(self, xt, t):
+        """-> tuple of G unit outputs [B, out_dim, F, H, W] (views of the session's static buffer: consume them
+        before the next call).  Partitioned sessions return the local units' outputs stacked instead."""
+        self.load(xt, t)
+        if len(self.units):
+            self._run("model", self._model_launches)
+        if not self.full:
+            return self.out
+        return tuple(self.out.view(self.G, self.B, *self.out.shape[1:])[g] for g in range(self.G))
+
+    # -- model + fused CFG / DDIM update ------------------------------------------------------------------
+    def ddim_step(self, xt, t, coef_tab, guide, mean_type, noise=None, clone=True):
+        """One denoise step.  coef_tab: [T+1, 7] fp32 table of the update's coefficients per integer timestep
+        (vgen_cfg_ddim_step); t [B] long.  Returns (x_{t-1}, x0): fresh tensors, or with clone=False the session's
+        own buffers (valid until the next step; passing that x_{t-1} back in skips the input copy)."""
+        assert self.full and self.G in (1, 2)
+        self.load(xt, t)
+        use_guide = self.G == 2
+        nz = None
+        if noise is not None:
+            nz = self._static.setdefault("noise", torch.empty_like(self.xt_1))
+            nz.copy_(noise)
+        key = ("ddim", id(coef_tab), float(guide), int(mean_type), noise is not None)
+        self._static[("tab",) + key] = coef_tab                     # keep the table alive while a graph reads it
+        outv = self.out.view(self.G, self.B, *self.out.shape[1:])
+
+        def launches():
+            self._model_launches()
+            ops.backend().ddim_update_units(self.x_units, self.G, self.B, self.C_lat, outv[0],
+                                            outv[1] if use_guide else None, nz, coef_tab, self.t_units[:self.B],
+                                            guide, use_guide, mean_type, self.xt_1, self.x0, replicate=True)
+
+        self._run(key, launches)
+        if clone:
+            return self.xt_1.clone(), self.x0.clone()
+        self._last_out = self.xt_1
+        return self.xt_1, self.x0
+
+
+class SessionCache:
+    """Small LRU of UnitSessions (a handful of prompts / kwarg sets in flight)."""
+
+    def __init__(self, capacity=4):
+        self.capacity = capacity
+        self._items = {}
+
+    def get(self, model, shape, device, kwargs_list, t_dtype, num_timesteps, units=None):
+        inner = getattr(model, "module", model)              # DistributedDataParallel wrapper of the engines
+        if not hasattr(inner, "_prepare_units") or not hasattr(inner, "_body"):
+            return None
+        key = (id(inner), inner._epoch, tuple(shape), str(device), _kw_key(kwargs_list), t_dtype, num_timesteps,
+               None if units is None else tuple(units), ops.backend().name)
+        s = self._items.pop(key, None)
+        if s is None:
+            try:
+                s = UnitSession(inner, tuple(shape), device, kwargs_list, t_dtype, num_timesteps, units)
+            except ValueError:
+                return None
+            while len(self._items) >= self.capacity:
+                self._items.pop(next(iter(self._items)))
+        self._items[key] = s
+        return s
+
+    def clear(self):
+        self._items.clear()
+
+
+def eval_units(cache, partition, model, xt, t, kwargs_list, num_timesteps=None):
+    """Model evaluation shared by the samplers: G kwarg sets on the latent batch xt as units -> tuple of G outputs
+    (partitioned over the ranks when `partition` is set, else one session replay), or None when `model` is not a
+    vgen_amd unit model (the caller then calls it branch by branch)."""
+    inner = getattr(model, "module", model)
+    if partition is not None:
+        return partition.run_units(inner, xt, t, list(kwargs_list), num_timesteps)
+    if xt.dim() == 5 and cache is not None:
+        nt = num_timesteps if t.dtype == torch.long else None
+        sess = cache.get(inner, tuple(xt.shape), xt.device, list(kwargs_list), t.dtype, nt)
+        if sess is not None:
+            return sess.eval(xt, t)
+    if hasattr(inner, "forward_units"):
+        return inner.forward_units(xt, t, list(kwargs_list))
+    return None

@@ -266,22 +266,25 @@ class UNetSD_T2VBase(nn.Module):
         nn.init.zeros_(self.out[-1].weight)
 
         self._packed = None
+        self._epoch = 0            # bumped whenever the parameters may have changed (sessions / caches key on it)
 
     def _stem_channels(self):
         return self.input_blocks[0][0].in_channels
 
     # -- packing -----------------------------------------------------------------------------
     def _apply(self, fn, *a, **k):
-        self._packed = None
+        self.invalidate()
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
-        self._packed = None
+        self.invalidate()
         return super().load_state_dict(*a, **k)
 
     def invalidate(self):
-        """Drop the packed 16-bit operands (call after editing parameters in place)."""
+        """Drop the packed 16-bit operands and everything derived from the parameters (call after editing
+        parameters in place); sampling sessions (vgen_amd/session.py) key on `_epoch`."""
         self._packed = None
+        self._epoch = getattr(self, "_epoch", 0) + 1
 
     def _resblocks(self):
         for blk in list(self.input_blocks) + [self.middle_block] + list(self.output_blocks):
@@ -302,21 +305,23 @@ class UNetSD_T2VBase(nn.Module):
         """Build the 16-bit tap-GEMM operands (once per weight load)."""
         dt = self.compute_dtype
         P = {}
+        # time (and fps) embedding MLPs and all 22 ResBlock emb_layers ([sum(Cout), embed_dim], one matrix) stay
+        # fp32: they see B rows per step (or are folded into a per-timestep table once, time_embedding_table) —
+        # 16-bit operands buy nothing there and their rounding reaches every ResBlock as a row bias
         te = self.time_embed
-        P["te0"] = (pack_linear(te[0].weight, dt), _f32(te[0].bias))
-        P["te2"] = (pack_linear(te[2].weight, dt), _f32(te[2].bias))
+        P["te0"] = (_f32(te[0].weight), _f32(te[0].bias))
+        P["te2"] = (_f32(te[2].weight), _f32(te[2].bias))
         if self.use_fps_condition:
             fe = self.fps_embedding
-            P["fe0"] = (pack_linear(fe[0].weight, dt), _f32(fe[0].bias))
-            P["fe2"] = (pack_linear(fe[2].weight, dt), _f32(fe[2].bias))
-        # all ResBlock emb_layers as one GEMM [sum(Cout), embed_dim]
+            P["fe0"] = (_f32(fe[0].weight), _f32(fe[0].bias))
+            P["fe2"] = (_f32(fe[2].weight), _f32(fe[2].bias))
         ws, bs, off = [], [], 0
         for rb in self._resblocks():
             ws.append(rb.emb_layers[1].weight)
             bs.append(rb.emb_layers[1].bias)
             rb._emb_off = off
             off += rb.cout
-        P["emb_all"] = (pack_linear(torch.cat(ws, 0), dt), _f32(torch.cat(bs, 0)))
+        P["emb_all"] = (_f32(torch.cat(ws, 0)), _f32(torch.cat(bs, 0)))
         # all cross-attention K/V projections as one GEMM [sum(2*inner), context_dim]
         ws, off = [], 0
         for st in self._spatial():
@@ -526,20 +531,37 @@ class UNetSD_T2VBase(nn.Module):
         return self._linear(t, P["pout"], M, residual=x, colstats=True)
 
     # -- forward -------------------------------------------------------------------------------
+    def _prepare_units(self, shape, device, kwargs_list):
+        """Everything ahead of the trunk for G kwarg sets evaluated on the same latent batch `shape` =
+        (B, C, F, H, W): G*B units, unit index g*B + b.  Returns None when the sets cannot share one batch, else
+        dict(extra=[G*B, C_extra, F, H, W] fp32 stem channels after the latent's (or None), ctx=[G*B (x F), L, D],
+        per_frame=bool, fps=[G*B] or None).  Only `x` and `t` change between the denoise steps of one prompt, so a
+        sampling session evaluates this ONCE (vgen_amd/session.py)."""
+        if any(kw.get("y") is None for kw in kwargs_list):
+            return None
+        fps = None
+        if self.use_fps_condition:
+            have = [kw.get("fps") is not None for kw in kwargs_list]
+            if any(have) and not all(have):
+                return None
+            if all(have):
+                fps = torch.cat([kw["fps"].reshape(-1).to(device) for kw in kwargs_list], 0)
+        ctx = torch.cat([kw["y"].to(device=device, dtype=torch.float32) for kw in kwargs_list], 0)
+        return dict(extra=None, ctx=ctx, per_frame=False, fps=fps)
+
     @torch.no_grad()
     def forward_units(self, x, t, kwargs_list):
         """Evaluate G independent kwarg sets (e.g. the cond / uncond pair of classifier-free
         guidance, diffusion_ddim.py:157-158) as ONE batch of G*B units: the 2.8 GB of weights
         stream from HBM once instead of G times.  Returns a tuple of G outputs."""
         G = len(kwargs_list)
-        if any(kw.get("y") is None for kw in kwargs_list):
+        prep = self._prepare_units(tuple(x.shape), x.device, kwargs_list)
+        if prep is None:
             return tuple(self.forward(x, t, **kw) for kw in kwargs_list)
-        extra = [{k: v for k, v in kw.items() if k not in ("y", "fps")} for kw in kwargs_list]
-        y = torch.cat([kw["y"] for kw in kwargs_list], 0)
-        fps = None
-        if all(kw.get("fps") is not None for kw in kwargs_list):
-            fps = torch.cat([kw["fps"].reshape(-1) for kw in kwargs_list], 0)
-        out = self.forward(x.repeat(G, 1, 1, 1, 1), t.repeat(G), y=y, fps=fps, **extra[0])
+        xs = x.float().repeat(G, 1, 1, 1, 1)
+        if prep["extra"] is not None:
+            xs = torch.cat([xs, prep["extra"]], 1)
+        out = self._trunk(xs, t.repeat(G), prep["ctx"], prep["fps"], ctx_per_frame=prep["per_frame"])
         return tuple(out.chunk(G, 0))
 
     @torch.no_grad()
@@ -549,38 +571,73 @@ class UNetSD_T2VBase(nn.Module):
         ctx = y if y is not None else self.zero_y.repeat(x.shape[0], 1, 1)[:, :1, :]
         return self._trunk(x, t, ctx, fps)
 
+    # -- the trunk in three pieces: (t, fps) -> row biases, context -> K/V, rows -> rows -------------------
+    def _embed_rows(self, tf, fpsf=None):
+        """[Embeddings]  unet_t2v.py:241-245 + every ResBlock's emb_layers (util.py:862-868) as ONE matrix:
+        timesteps tf [n] (fp32) -> [n, sum(Cout)] fp32 row biases (the repeat_interleave over frames is never
+        materialised: the per-(b) row-bias is broadcast inside the conv epilogue).  n rows of a 320 -> 1280 ->
+        1280 -> sum(Cout) MLP: fp32 (vgen_linear_f32) on the fp32 parameters; sinusoid: util.py:178-190."""
+        be = ops.backend()
+        P = self._packed
+        dev = P["te0"][0].device
+
+        def mlp(val, w0, w2, add=None):
+            s = be.timestep_embedding(val.to(device=dev, dtype=torch.float32).reshape(-1).contiguous(), self.dim,
+                                      torch.float32)
+            return be.linear_f32(be.linear_f32(s, *w0), *w2, act_in=1, add=add)
+
+        e = mlp(tf, P["te0"], P["te2"])
+        if self.use_fps_condition and fpsf is not None:
+            e = mlp(fpsf, P["fe0"], P["fe2"], add=e)
+        return be.linear_f32(e, *P["emb_all"], act_in=1)            # emb_layers[0] = SiLU
+
+    def _embed(self, t, fps, B, dev):
+        return self._embed_rows(t, fps)
+
+    @torch.no_grad()
+    def time_embedding_table(self, n, device=None):
+        """Row biases of every integer timestep 0..n-1 ([n, sum(Cout)] fp32) — a function of the WEIGHTS only, so it
+        is folded once per weight load like the packed operands.  The reference re-evaluates this MLP on every
+        step (unet_t2v.py:93-96,244-245); a sampling session gathers row t instead.  Only without the fps
+        condition (there the SiLU sees time + fps embedding)."""
+        if self._packed is None:
+            self.pack()
+        P = self._packed
+        key = ("emb_tab", n)
+        if key not in P:
+            P[key] = self._embed_rows(torch.arange(n, dtype=torch.float32))
+        return P[key]
+
+    def _context_kv(self, ctx, dev):
+        """K and V projections of all 16 cross-attention blocks as one GEMM over the context rows
+        (util.py:233-235).  They depend on the prompt only: a sampling session keeps them across steps."""
+        be = ops.backend()
+        dt = self.compute_dtype
+        nctx, Lctx = ctx.shape[0], ctx.shape[1]
+        ctx16 = be.act_cast(ctx.to(device=dev, dtype=torch.float32).reshape(nctx * Lctx, -1).contiguous(), 0, dt)
+        return self._linear(ctx16, self._packed["kv_all"], nctx * Lctx, out_dtype=dt)
+
     def _trunk(self, x, t, ctx, fps=None, ctx_per_frame=False):
         """Embeddings + encoder / middle / decoder / head on rows (unet_t2v.py:241-277).  `x` carries every
         input channel of the stem conv ([B, C, F, H, W]), `ctx` every cross-attention token: [B, L, 1024] shared
         by the frames of a video, or [B * F, L, 1024] with ctx_per_frame (frame-major per prompt)."""
-        be = ops.backend()
-        dt = self.compute_dtype
         if self._packed is None:
             self.pack()
+        B, C, F, H, W = x.shape
+        assert ctx.shape[0] == (B * F if ctx_per_frame else B), (tuple(ctx.shape), B, F, ctx_per_frame)
+        emb_all = self._embed(t, fps, B, x.device)
+        kv_all = self._context_kv(ctx, x.device)
+        return self._body(x, emb_all, kv_all, ctx.shape[1], ctx_per_frame)
+
+    def _body(self, x, emb_all, kv_all, Lctx, ctx_per_frame=False, out=None):
+        """Stem conv, encoder / middle / decoder, head: rows in, [B, out_dim, F, H, W] fp32 out (into `out`)."""
+        be = ops.backend()
+        dt = self.compute_dtype
         P = self._packed
         B, C, F, H, W = x.shape
         assert C == self._stem_channels()
         dev = x.device
         x = x.float().contiguous()
-
-        # [Embeddings]  unet_t2v.py:241-245 (the repeat_interleave over frames is never materialised:
-        # the per-(b) row-bias is broadcast inside the conv epilogue)
-        def emb_mlp(val, w0, w2):
-            s = be.timestep_embedding(val.to(device=dev, dtype=torch.float32).reshape(-1).contiguous(), self.dim, dt)
-            h = self._linear(s, w0, B)
-            return self._linear(be.act_cast(h, 1, dt), w2, B)
-
-        e = emb_mlp(t, P["te0"], P["te2"])
-        if self.use_fps_condition and fps is not None:
-            e = e + emb_mlp(fps, P["fe0"], P["fe2"])
-        es = be.act_cast(e, 1, dt)                                  # emb_layers[0] = SiLU
-        emb_all = self._linear(es, P["emb_all"], B)                 # [B, sum(Cout)] fp32
-
-        Lctx = ctx.shape[1]
-        nctx = ctx.shape[0]
-        assert nctx == (B * F if ctx_per_frame else B), (tuple(ctx.shape), B, F, ctx_per_frame)
-        ctx16 = be.act_cast(ctx.to(device=dev, dtype=torch.float32).reshape(nctx * Lctx, -1).contiguous(), 0, dt)
-        kv_all = self._linear(ctx16, P["kv_all"], nctx * Lctx, out_dtype=dt)
 
         # input conv: im2col of the [B,C,F,H,W] latent straight into rows
         if C % 64 == 0:
@@ -635,7 +692,9 @@ class UNetSD_T2VBase(nn.Module):
         # head: GroupNorm + SiLU + Conv 3x3 -> out_dim, then rows -> [B, out_dim, F, H, W]
         a, _ = be.groupnorm(h, None, B * F, H * W, 32, 1e-5, *P["head_gn"], True, False, dt)
         o, _, _ = self._conv3x3(a, P["head_conv"], B * F, H, W, h.shape[1])
-        out = torch.empty((B, self.out_dim, F, H, W), dtype=torch.float32, device=dev)
+        if out is None:
+            out = torch.empty((B, self.out_dim, F, H, W), dtype=torch.float32, device=dev)
+        assert out.shape == (B, self.out_dim, F, H, W) and out.dtype == torch.float32 and out.is_contiguous()
         od = self.out_dim
         sFHW = F * H * W
         be.pointwise_small(o, B * F, F, od, H, W, (sFHW * od, H * W * od, 1, W * od, od),

@@ -174,19 +174,16 @@ class UNetSD_I2VGen(UNetSD_T2VBase):
         concat, extra = self.condition_stems(local_image, image, B, F, H, W)
         return self._with_stems(x, t, y, concat, extra, fps)
 
-    def forward_units(self, x, t, kwargs_list):
-        """CFG pair as one batch (see UNetSD_T2VBase.forward_units).  The stems are evaluated (and cached) per
-        unit on the caller's own conditioning tensors, then stacked."""
-        G = len(kwargs_list)
+    def _prepare_units(self, shape, device, kwargs_list):
+        """CFG units of one latent batch (see UNetSD_T2VBase._prepare_units).  The stems are evaluated (and cached)
+        per unit on the caller's own conditioning tensors, then stacked."""
         if any(kw.get("y") is None or kw.get("local_image") is None or kw.get("fps") is None for kw in kwargs_list):
-            return tuple(self.forward(x, t, **kw) for kw in kwargs_list)
-        B, C, F, H, W = x.shape
+            return None
+        B, C, F, H, W = shape
         stems = [self.condition_stems(kw["local_image"], kw.get("image"), B, F, H, W) for kw in kwargs_list]
         if len({s[1].shape[1] for s in stems}) != 1:
-            return tuple(self.forward(x, t, **kw) for kw in kwargs_list)
-        concat = torch.cat([s[0] for s in stems], 0)
-        extra = torch.cat([s[1] for s in stems], 0)
-        y = torch.cat([kw["y"] for kw in kwargs_list], 0)
-        fps = torch.cat([kw["fps"].reshape(-1) for kw in kwargs_list], 0)
-        out = self._with_stems(x.repeat(G, 1, 1, 1, 1), t.repeat(G), y, concat, extra, fps)
-        return tuple(out.chunk(G, 0))
+            return None
+        extra = torch.cat([s[1].to(device) for s in stems], 0)
+        y = torch.cat([kw["y"].to(device=device, dtype=torch.float32) for kw in kwargs_list], 0)
+        return dict(extra=torch.cat([s[0].to(device) for s in stems], 0), ctx=torch.cat([y, extra], 1), per_frame=False,
+                    fps=torch.cat([kw["fps"].reshape(-1).to(device) for kw in kwargs_list], 0))

@@ -37,6 +37,9 @@ _SPATIAL = {
     "single_sketch": ("single_sketch", "single_sketch_embedding", "single_sketch_embedding_after", 1),
     "local_image": ("local_image", "local_image_embedding", "local_image_embedding_after", 3),
 }
+# order in which the reference accumulates the maps into `concat` (unet_videolcm.py:599-699): the fp32 sum is
+# order-dependent, so the same order keeps three or more active compositions bit-comparable with the oracle
+_ACCUMULATION_ORDER = ("depthmap", "local_image", "motion", "canny", "sketch", "single_sketch", "mask")
 _UNSUPPORTED = ()
 _SUPPORTED_COMPOSITIONS = ("text", "image", "histogram") + tuple(_SPATIAL)
 
@@ -110,6 +113,13 @@ class _ComposerTrunk(UNetSD_T2VBase):
         self._pic = None
         self._stem_cache = {}
 
+    def invalidate(self):
+        """Parameters (may) have changed or moved: drop the packed operands AND every cached stem output."""
+        super().invalidate()
+        self._pic = None
+        self._zeros = None
+        self._stem_cache = {}
+
     def _image_tokens(self, image, B):
         be, dt = ops.backend(), self.compute_dtype
         if self._pic is None:
@@ -150,7 +160,8 @@ class _ComposerTrunk(UNetSD_T2VBase):
         if self._packed is None:
             self.pack()
         concat = None
-        for name, (kwarg, stem, after, cin) in _SPATIAL.items():        # the reference's order of accumulation
+        for name in _ACCUMULATION_ORDER:                                # the reference's order of accumulation
+            kwarg, stem, after, cin = _SPATIAL[name]
             cond = conds.get(kwarg)
             if cond is None:
                 continue
@@ -194,24 +205,20 @@ class _ComposerTrunk(UNetSD_T2VBase):
         concat, ctx, per_frame = self._prepare(tuple(x.shape), x.device, **kw)
         return self._trunk(torch.cat([x.float(), concat], 1), t, ctx, kw.get("fps"), ctx_per_frame=per_frame)
 
-    def forward_units(self, x, t, kwargs_list):
-        """CFG pair as one batch of units (see UNetSD_T2VBase.forward_units): stems / context are prepared per
+    def _prepare_units(self, shape, device, kwargs_list):
+        """CFG units of one latent batch (see UNetSD_T2VBase._prepare_units): stems / context are prepared per
         unit on the caller's own conditioning tensors (cached), then stacked along the batch."""
-        G = len(kwargs_list)
-        prep = [self._prepare(tuple(x.shape), x.device, **kw) for kw in kwargs_list]
+        prep = [self._prepare(tuple(shape), device, **kw) for kw in kwargs_list]
         same = len({(p[1].shape[1], p[2]) for p in prep}) == 1 and \
             len({kw.get("fps") is None for kw in kwargs_list}) == 1
         if not same:
-            return tuple(self.forward(x, t, **kw) for kw in kwargs_list)
-        B, F = x.shape[0], x.shape[2]
-        concat = torch.cat([p[0] for p in prep], 0)
-        ctx = torch.cat([p[1] for p in prep], 0)             # per-frame contexts are frame-major per prompt: cat is right
+            return None
         fps = None
-        if kwargs_list[0].get("fps") is not None:
-            fps = torch.cat([kw["fps"].reshape(-1) for kw in kwargs_list], 0)
-        out = self._trunk(torch.cat([x.float().repeat(G, 1, 1, 1, 1), concat], 1), t.repeat(G), ctx, fps,
-                          ctx_per_frame=prep[0][2])
-        return tuple(out.chunk(G, 0))
+        if self.use_fps_condition and kwargs_list[0].get("fps") is not None:
+            fps = torch.cat([kw["fps"].reshape(-1).to(device) for kw in kwargs_list], 0)
+        # per-frame contexts are frame-major per prompt: cat along dim 0 is right
+        return dict(extra=torch.cat([p[0] for p in prep], 0), ctx=torch.cat([p[1] for p in prep], 0),
+                    per_frame=prep[0][2], fps=fps)
 
 
 def _trunk_kwargs(loc):
