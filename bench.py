@@ -1,4 +1,4 @@
-"""bench.py — denoise-steps/sec of the t2v sampling hot path on MI355X (BASELINE.json metric).
+"""bench.py — denoise-steps/sec of the sampling hot path on MI355X (BASELINE.json metric).
 
     python bench.py --gpus 1 --steps 10 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -10,22 +10,34 @@ UNetSD_T2VBase 1411 M parameters): two UNet forwards (evaluated as one batch of 
 fused CFG/DDIM update, with all inputs resident in HBM.  Synthetic latents/context, seeded
 random-init weights (no checkpoints offline).
 
+The timed region calls the PUBLIC sampler API the engines use, step by step:
+`DiffusionDDIM.ddim_sample(xt, t, model, [cond, uncond], guide_scale=9, ddim_timesteps=50, eta=0)`
+(`ddim_sample_loop` is a loop over exactly this call; tools/inferences/inference_text2video_entrance.py:200-206),
+each call's x_{t-1} fed to the next, t walking the 50-step DDIM schedule.  Underneath, a cached sampling
+session (vgen_amd/session.py) replays one hipGraph per step; the untimed setup does two steps (eager
+warm-up + capture), like weight loading.
+
+Operand dtype: fp16 by default — the arithmetic the reference itself runs (`use_fp16: True`, autocast) and the
+16-bit type whose UNet output is closest to the fp32 reference (profiles/r02_parity.json); `--dtype bf16`
+runs BASELINE.json's literal "bf16" (same MFMA rate, 8x the rounding error).
+
 N > 1 (weak scaling): P = N prompts in flight -> 2N units spread over the ranks (unit u -> rank
 u % N), ONE all-gather of the unit outputs per step (RCCL), every rank applies the cheap update for
-all prompts.  value = prompts * steps / max-over-ranks time.  The local units' forward is replayed as a
-hipGraph (vgen_amd.graph.GraphedForward); the all-gather and the update stay eager.  `--partition`
-runs that same code path at N = 1.
+all prompts.  value = prompts * steps / max-over-ranks time.  `--partition` runs that code path at N = 1.
+
+`--config {i2vgen,sr600,tft2v896,tft2v32f,videolcm}` runs the other BASELINE.json shapes through
+the same API (random-init weights of that architecture; see CONFIGS).
 
 Extra objects on the JSON line:
   roofline     — dominant kernel (tap-GEMM, MFMA-bound): algorithmic FLOP per launch / average launch
-                 duration, measured with HIP events on the launch stream in an instrumented pass of
-                 the same step; peak = 2.5 PFLOP/s dense 16-bit MFMA.
-                 `traffic` = HBM-side bytes per launch from the committed rocprofv3 PMC passes of this
-                 command (profiles/r01_tapgemm_traffic.json; tools/collect_evidence.sh regenerates them).
+                 duration, measured with HIP events on the launch stream in an instrumented eager pass of
+                 the same step; peak = 2.5 PFLOP/s dense 16-bit MFMA.  `traffic` = HBM-side bytes per launch
+                 from the committed rocprofv3 PMC passes of this command (profiles/, tools/collect_evidence.sh).
+  hbm_kernels  — GroupNorm / LayerNorm launches of the same pass: algorithmic bytes / time vs 8 TB/s.
   cpu_baseline — the oracle (CPU port of the reference forward, oracle/torch_ref.py) timed on the
-                 host cores on a bounded sample (full-size UNet, 4-frame latent, 32 threads), scaled to
-                 a full step; rank 0 at N=1.
-  vae          — AutoencoderKL decode frames/s at 256x448 (decoder_bs = 2 like t2v_infer.yaml).
+                 host cores on a bounded sample, scaled to a full step; rank 0 at N=1.
+  vae / e2e    — AutoencoderKL decode frames/s; a whole video (50-step ddim_sample_loop + 16-frame decode).
+  parity       — UNet rel-L2 vs the reference's fp32 forward for this dtype (from the committed GPU-test record).
 """
 from __future__ import annotations
 
@@ -48,9 +60,35 @@ VAE_SD = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch
               ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)
 DDIM = dict(schedule="cosine", schedule_param=dict(num_timesteps=1000, cosine_s=0.008, zero_terminal_snr=True),
             mean_type="v", loss_type="mse", var_type="fixed_small", rescale_timesteps=False)
-UNET_FWD_TFLOP = 8.665      # one forward, B=1, [1,4,16,32,56], ctx 77 (FlopCounterMode)
-VAE_DEC_TFLOP = 1.092       # per 256x448 frame
+VAE_DEC_TFLOP = 1.092       # per 256x448 frame (SURVEY.md §8d)
 PEAK_TFLOPS = 2500.0        # dense bf16/fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0
+
+# name -> (model class path, ctor kwargs, latent [C,F,H,W], units per step G, UNet forward TFLOP,
+#          extra conditioning builder, description)
+CONFIGS = {
+    "t2v": dict(cls="unet.UNetSD_T2VBase", cfg=UNET_T2V, latent=(4, 16, 32, 56), G=2, tflop=8.665,
+                desc="t2v 16x448x256 latent [1,4,16,32,56], DDIM CFG step (2 UNetSD_T2VBase fwd + fused update), "
+                     "guide 9, 77x1024 ctx, random-init 1411M params"),
+    "i2vgen": dict(cls="unet_i2vgen.UNetSD_I2VGen", cfg=dict(UNET_T2V, concat_dim=4, upper_len=128, default_fps=8),
+                   latent=(4, 16, 88, 160), G=2, tflop=88.09,
+                   desc="i2vgen-xl 16x1280x704 latent [1,4,16,88,160], DDIM CFG step (2 UNetSD_I2VGen fwd + update), "
+                        "77+64+4 ctx tokens, local-image stem channels"),
+    "sr600": dict(cls="unet.UNetSD_SR600", cfg=dict(UNET_T2V, use_scale_shift_norm=True, inpainting=True),
+                  latent=(4, 32, 90, 160), G=2, tflop=185.80,
+                  desc="sr600 32x1280x720 latent [1,4,32,90,160], CFG step (2 UNetSD_SR600 fwd + fused update), "
+                       "pad-(2,1) downsample / cropped upsample / FreeU"),
+    "tft2v896": dict(cls="unet_videolcm.UNetSD_TFT2V", cfg=dict(UNET_T2V, num_tokens=4), comps=["text", "image"],
+                     latent=(4, 16, 64, 112), G=2, tflop=38.97,
+                     desc="tft2v 16x896x512 latent [1,4,16,64,112], DDIM CFG step (2 UNetSD_TFT2V fwd + update), text+image"),
+    "tft2v32f": dict(cls="unet_videolcm.UNetSD_TFT2V", cfg=dict(UNET_T2V, num_tokens=4), comps=["text", "image"],
+                     latent=(4, 32, 32, 56), G=2, tflop=17.36,
+                     desc="tft2v 32x448x256 latent [1,4,32,32,56], DDIM CFG step (2 UNetSD_TFT2V fwd + update), text+image"),
+    "videolcm": dict(cls="unet_videolcm.UNetSD_VideoLCM", cfg=dict(UNET_T2V), comps=["text"],
+                     latent=(4, 16, 32, 56), G=1, tflop=8.665,
+                     desc="videolcm 16x448x256 latent [1,4,16,32,56], one UNetSD_VideoLCM fwd + fused update per step "
+                          "(no CFG, as the 4-step LCM loop)"),
+}
 
 
 def randomize_(module, seed):
@@ -67,27 +105,68 @@ def randomize_(module, seed):
                 p.copy_(0.1 * torch.randn(p.shape, generator=g, device=p.device))
 
 
+def build_model(name, dev, dtype):
+    import importlib
+    import types
+    c = CONFIGS[name]
+    modname, clsname = c["cls"].split(".")
+    cls = getattr(importlib.import_module("vgen_amd." + modname), clsname)
+    kw = dict(c["cfg"])
+    if "comps" in c:
+        kw["config"] = types.SimpleNamespace(video_compositions=c["comps"], resolution=[c["latent"][3] * 8, c["latent"][2] * 8])
+    with torch.device(dev):
+        model = cls(**kw, compute_dtype=dtype)
+    model.eval()
+    randomize_(model, 0)
+    model.pack()
+    return model
+
+
+def conditioning(name, model, P, dev, gen):
+    """[cond kwargs, uncond kwargs] (or one set) with the tensors the engines pass for this model family."""
+    c = CONFIGS[name]
+    C, F, H, W = c["latent"]
+    y_c = torch.randn(P, 77, 1024, generator=gen, device=dev)
+    y_u = torch.randn(P, 77, 1024, generator=gen, device=dev)
+    kc, ku = dict(y=y_c), dict(y=y_u)
+    if name == "i2vgen":
+        img = torch.randn(P, 1024, generator=gen, device=dev)
+        li = torch.randn(P, 4, 1, H, W, generator=gen, device=dev)
+        fps = torch.full((P,), 8, dtype=torch.long, device=dev)
+        kc.update(image=img.unsqueeze(1), local_image=li, fps=fps)
+        ku.update(image=torch.zeros_like(img).unsqueeze(1), local_image=li, fps=fps)
+    if name in ("tft2v896", "tft2v32f"):
+        img = torch.randn(P, 1, 1024, generator=gen, device=dev)
+        kc.update(image=img)
+        ku.update(image=torch.zeros_like(img))
+    return [kc, ku] if c["G"] == 2 else [kc]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16"])
+    ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16"])
+    ap.add_argument("--config", default="t2v", choices=sorted(CONFIGS))
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--partition", action="store_true",
-                    help="use the multi-GPU code path (UnitPartition + graphed local forward + eager gather/update) "
-                         "even at --gpus 1")
-    ap.add_argument("--dump-shapes", action="store_true", help="write per-shape tap-GEMM timings to gpurun_out/")
+                    help="use the multi-GPU code path (UnitPartition: session over the local units + eager "
+                         "gather/update) even at --gpus 1")
+    ap.add_argument("--vae-size", default="256x448", help="HxW of the decoded frame")
+    ap.add_argument("--dump-shapes", action="store_true", help="write per-shape kernel timings to gpurun_out/")
     args = ap.parse_args()
+    if args.no_graph:
+        os.environ["VGEN_GRAPH"] = "0"
 
     import torch.distributed as dist
     from vgen_amd import ops
     from vgen_amd.diffusion import DiffusionDDIM
     from vgen_amd.parallel import UnitPartition
-    from vgen_amd.unet import UNetSD_T2VBase
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -101,11 +180,10 @@ def main():
     ops.set_backend(None)
     assert ops.backend().name == "hip"
 
-    with torch.device(dev):
-        model = UNetSD_T2VBase(**UNET_T2V, compute_dtype=args.dtype)
-    model.eval()
-    randomize_(model, 0)
-    model.pack()
+    cfg = CONFIGS[args.config]
+    C, F, H, W = cfg["latent"]
+    G = cfg["G"]
+    model = build_model(args.config, dev, args.dtype)
     for p in model.parameters():                      # fp32 masters are not needed for sampling
         p.data = torch.empty(0, device=dev)
     torch.cuda.empty_cache()
@@ -114,66 +192,40 @@ def main():
     diff.rng_parity = False
     P = world                                           # prompts in flight (weak scaling)
     g = torch.Generator(device=dev).manual_seed(8888)
-    xt = torch.randn(P, 4, 16, 32, 56, generator=g, device=dev)
-    y_c = torch.randn(P, 77, 1024, generator=g, device=dev)
-    y_u = torch.randn(P, 77, 1024, generator=g, device=dev)
-    kw = [dict(y=y_c), dict(y=y_u)]
+    xt0 = torch.randn(P, C, F, H, W, generator=g, device=dev)
+    kw = conditioning(args.config, model, P, dev, g)
+    guide = 9.0 if G == 2 else None
+    mkw = kw if G == 2 else kw[0]
     steps_all = (1 + torch.arange(0, 1000, 20)).clamp(0, 999).flip(0).tolist()
     part = UnitPartition() if (world > 1 or args.partition) else None
     diff.partition = part
-    step_model = model
-    if part is not None and not args.no_graph:
-        # the RCCL all-gather stays outside the graph: replay the local units' forward, then gather + update
-        from vgen_amd.graph import GraphedForward
-        step_model = GraphedForward(model, warmup=1)
+    t_bufs = {}
 
-    state = {"xt": xt}
-    t_buf = torch.full((P,), steps_all[0], dtype=torch.long, device=dev)
+    def t_of(i):
+        s = steps_all[i % len(steps_all)]
+        if s not in t_bufs:
+            t_bufs[s] = torch.full((P,), s, dtype=torch.long, device=dev)
+        return t_bufs[s]
 
-    def one_step():
-        state["xt"], _ = diff.ddim_sample(state["xt"], t_buf, step_model, kw, guide_scale=9.0,
-                                          ddim_timesteps=50, eta=0.0)
+    for i in range(len(steps_all)):                     # untimed: the 50 timestep tensors of the schedule
+        t_of(i)
 
-    use_graph = (not args.no_graph) and part is None
-    graph = None
-    static_in = None
-    if use_graph:
-        static_in = xt.clone()
-        s = torch.cuda.Stream()
-        s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            for _ in range(2):
-                diff.ddim_sample(static_in, t_buf, model, kw, guide_scale=9.0, ddim_timesteps=50, eta=0.0)
-        torch.cuda.current_stream().wait_stream(s)
-        torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_out, _ = diff.ddim_sample(static_in, t_buf, model, kw, guide_scale=9.0,
-                                             ddim_timesteps=50, eta=0.0)
+    def step(xt, i):
+        return diff.ddim_sample(xt, t_of(i), model, mkw, guide_scale=guide, ddim_timesteps=50, eta=0.0)[0]
 
-        def one_step():  # noqa: F811
-            graph.replay()
-            static_in.copy_(static_out)
-
-    def set_t(i):
-        t_buf.fill_(steps_all[i % len(steps_all)])
-
-    if step_model is not model:      # untimed: eager pass + capture of the local forward (like the N=1 capture above)
-        for _ in range(2):
-            one_step()
-        state["xt"] = xt
-
+    xt = xt0
+    for i in range(2):                                  # untimed setup: eager warm-up pass + graph capture
+        xt = step(xt, i)
+    xt = xt0
     for i in range(args.warmup):
-        set_t(i)
-        one_step()
+        xt = step(xt, i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        set_t(args.warmup + i)
-        one_step()
+        xt = step(xt, args.warmup + i)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -183,9 +235,12 @@ def main():
         tt = torch.tensor([dt_s], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt_s = float(tt.item())
-    xt_end = state["xt"] if not use_graph else static_in
-    finite = bool(torch.isfinite(xt_end).all())
-    xt_absmax = float(xt_end.float().abs().nan_to_num(nan=float("inf")).max())
+    finite = bool(torch.isfinite(xt).all())
+    xt_absmax = float(xt.float().abs().nan_to_num(nan=float("inf")).max())
+    sess = None
+    cache = part.sessions if part is not None else diff.sessions
+    if cache is not None and cache._items:
+        sess = next(iter(cache._items.values()))
 
     steps_per_s = P * args.steps / dt_s
     res = {
@@ -193,44 +248,58 @@ def main():
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt_s / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "t2v 16x448x256 latent [1,4,16,32,56], DDIM CFG step (2 UNetSD_T2VBase fwd "
-                               "+ fused update), guide 9, 77x1024 ctx, random-init 1411M params",
-                   "prompts_in_flight": P, "units_per_step": 2 * P,
+        "config": {"workload": cfg["desc"], "name": args.config,
+                   "prompts_in_flight": P, "units_per_step": G * P,
+                   "api": "DiffusionDDIM.ddim_sample per step (public sampler API; cached sampling session underneath)",
                    "parallelism": "single GPU" if world == 1 else f"unit partition over {world} ranks, 1 all-gather/step",
-                   "hipgraph": "whole step" if use_graph else ("local forward" if step_model is not model else False)},
+                   "hipgraph": bool(sess is not None and sess.use_graph and sess._graphs) and
+                   ("whole step" if part is None else "local units' forward")},
         "finite": finite, "latent_absmax_after_timed_steps": xt_absmax,
-        "model_tflops_per_s": round(2 * UNET_FWD_TFLOP * steps_per_s, 2),
+        "model_tflops_per_s": round(G * cfg["tflop"] * steps_per_s, 2),
+        "frac_of_mfma_peak": round(G * cfg["tflop"] * steps_per_s / world / PEAK_TFLOPS, 4),
     }
+    ppath = os.path.join(ROOT, "profiles", "r02_parity.json")
+    if os.path.exists(ppath) and args.config == "t2v":
+        pj = json.load(open(ppath))
+        key = f"unet_t2v_full/{args.dtype}"
+        if key in pj:
+            res["parity"] = {"dtype": args.dtype, "unet_rel_l2": pj[key],
+                             "reference_own_autocast_rel_l2": pj.get(f"reference_autocast/{args.dtype}"),
+                             "source": "profiles/r02_parity.json (tests/test_gpu_model.py on MI355X, full-size golden "
+                                       "from the reference's fp32 forward)"}
 
     # ---- roofline of the dominant kernel (instrumented eager pass, same step) ----------------------
     if rank == 0 and not args.no_roofline:
+        d0 = DiffusionDDIM(**DDIM)
+        d0.rng_parity = False
+        d0.sessions = None                              # step-by-step launches: every kernel bracketed by HIP events
+        xs = xt0[:1].clone()
+        kw1 = [{k: (v[:1] if torch.is_tensor(v) else v) for k, v in d.items()} for d in kw]
+        mk1 = kw1 if G == 2 else kw1[0]
+        d0.ddim_sample(xs, t_of(0)[:1], model, mk1, guide_scale=guide, ddim_timesteps=50, eta=0.0)
         ops.KERNEL_PROFILE = []
-        xs = xt[:1].clone()
-        kw1 = [dict(y=y_c[:1]), dict(y=y_u[:1])]
-        diff.partition = None
         torch.cuda.synchronize()
         torch.cuda._sleep(int(4e8))     # let the host run ahead so event pairs bracket GPU time only
-        diff.ddim_sample(xs, t_buf[:1], model, kw1, guide_scale=9.0, ddim_timesteps=50, eta=0.0)
+        d0.ddim_sample(xs, t_of(0)[:1], model, mk1, guide_scale=guide, ddim_timesteps=50, eta=0.0)
         torch.cuda.synchronize()
         allrecs = ops.KERNEL_PROFILE
         ops.KERNEL_PROFILE = None
         recs = [r for r in allrecs if r[0] == "tapgemm"]
-        diff.partition = part
         ms = [r[1].elapsed_time(r[2]) for r in recs]
         fl = [r[3] for r in recs]
+        other = {}
+        for r in allrecs:
+            if r[0] == "tapgemm":
+                continue
+            a = other.setdefault((r[0],) + tuple(r[4]), [0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += r[1].elapsed_time(r[2])
+            a[2] += r[3]
         if args.dump_shapes:
-            other = {}
-            for r in allrecs:
-                if r[0] == "tapgemm":
-                    continue
-                a = other.setdefault((r[0],) + tuple(r[4]), [0, 0.0, 0.0])
-                a[0] += 1
-                a[1] += r[1].elapsed_time(r[2])
-                a[2] += r[3]
             orows = sorted(([list(k), v[0], round(v[1], 4), round(v[2] / (v[1] * 1e-3) / 1e9, 1)] for k, v in other.items()),
                            key=lambda r: -r[2])
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-            with open(os.path.join(ROOT, "gpurun_out", "other_shapes.json"), "w") as f:
+            with open(os.path.join(ROOT, "gpurun_out", f"other_shapes_{args.config}.json"), "w") as f:
                 json.dump({"cols": ["(op,shape...)", "launches", "ms", "GB/s or GFLOP/s"], "rows": orows}, f, indent=0)
             agg = {}
             for r, m in zip(recs, ms):
@@ -240,8 +309,7 @@ def main():
                 a[2] += r[3]
             rows = sorted(([list(k), v[0], round(v[1], 4), round(v[2] / (v[1] * 1e-3) / 1e12, 1)] for k, v in agg.items()),
                           key=lambda r: -r[2])
-            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-            with open(os.path.join(ROOT, "gpurun_out", "tapgemm_shapes.json"), "w") as f:
+            with open(os.path.join(ROOT, "gpurun_out", f"tapgemm_shapes_{args.config}.json"), "w") as f:
                 json.dump({"cols": ["(mode,M,N,K,epi,out)", "launches", "ms", "TFLOP/s"], "rows": rows}, f, indent=0)
         tot_ms, tot_fl = sum(ms), sum(fl)
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
@@ -253,20 +321,37 @@ def main():
                            "tapgemm_ms_per_step": round(tot_ms, 3)}
         # HBM-side bytes per launch cannot be read from inside the process: they come from the committed
         # rocprofv3 PMC passes of this same command (tools/collect_evidence.sh -> profiles/)
-        tpath = os.path.join(ROOT, "profiles", "r01_tapgemm_traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            res["roofline"]["traffic"] = round(tj["hbm_bytes_per_launch"])
-            res["roofline"]["traffic_unit"] = "bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/r01_tapgemm_traffic.json)"
+        for tname in ("r02_tapgemm_traffic.json", "r01_tapgemm_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                res["roofline"]["traffic"] = round(tj["hbm_bytes_per_launch"])
+                res["roofline"]["traffic_unit"] = f"bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/{tname})"
+                if "mfma_busy_frac" in tj:
+                    res["roofline"]["mfma_busy_frac"] = tj["mfma_busy_frac"]
+                break
+        # the HBM-bound kernel classes of the same pass, against chip peak (north_star: "HBM GB/s ... against chip peak")
+        hk = {}
+        for k, v in other.items():
+            if k[0] in ("groupnorm", "layernorm"):
+                a = hk.setdefault(k[0], [0, 0.0, 0.0])
+                a[0] += v[0]
+                a[1] += v[1]
+                a[2] += v[2]
+        res["hbm_kernels"] = {k: {"launches": v[0], "ms_per_step": round(v[1], 3),
+                                  "achieved_GBs": round(v[2] / (v[1] * 1e-3) / 1e9, 1),
+                                  "frac_of_8TBs": round(v[2] / (v[1] * 1e-3) / 1e9 / PEAK_HBM_GBS, 3)}
+                              for k, v in hk.items() if v[1] > 0}
 
-    # ---- VAE decode frames/s ---------------------------------------------------------------------------
+    # ---- VAE decode frames/s + a whole video end to end --------------------------------------------------
     if rank == 0 and not args.no_vae:
         from vgen_amd.vae import AutoencoderKL
+        fh, fw = (int(v) for v in args.vae_size.split("x"))
         with torch.device(dev):
             vae = AutoencoderKL(ddconfig=VAE_SD, embed_dim=4, compute_dtype=args.dtype)
         vae.eval()
         randomize_(vae, 1)
-        z = torch.randn(2, 4, 32, 56, device=dev) / 0.18215 * 0.2
+        z = torch.randn(2, 4, fh // 8, fw // 8, device=dev) / 0.18215 * 0.2
         for _ in range(2):
             vae.decode(z)
         torch.cuda.synchronize()
@@ -276,8 +361,24 @@ def main():
             vae.decode(z)
         torch.cuda.synchronize()
         fps = 2 * nrep / (time.perf_counter() - t1)
-        res["vae"] = {"decode_frames_per_sec": round(fps, 2), "frame": "256x448", "decoder_bs": 2,
-                      "tflops_per_s": round(fps * VAE_DEC_TFLOP, 2)}
+        res["vae"] = {"decode_frames_per_sec": round(fps, 2), "frame": args.vae_size, "decoder_bs": 2}
+        if args.vae_size == "256x448":
+            res["vae"]["tflops_per_s"] = round(fps * VAE_DEC_TFLOP, 2)
+        if not args.no_e2e and world == 1 and part is None and args.config == "t2v":
+            # the engine's whole job for one prompt (inference_text2video_entrance.py:194-217): 50-step
+            # ddim_sample_loop + 16 frames decoded 2 at a time to uint8 video
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            lat = diff.ddim_sample_loop(xt0, model, mkw, guide_scale=guide, ddim_timesteps=50, eta=0.0)
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            vid = vae.decode_video(lat * 0.2, scale_factor=0.18215, decoder_bs=2)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            res["e2e"] = {"video": "16 frames 448x256, 50 DDIM CFG steps + AutoencoderKL decode to uint8",
+                          "loop50_s": round(t2 - t1, 4), "loop50_steps_per_sec": round(50 / (t2 - t1), 3),
+                          "decode16_s": round(t3 - t2, 4),
+                          "frames_per_sec": round(F / (t3 - t1), 3), "video_shape": list(vid.shape)}
         del vae
 
     # ---- CPU baseline: the oracle on host cores, bounded sample -------------------------------------------
@@ -285,7 +386,7 @@ def main():
     # 16-frame forward (conv/linear FLOPs are proportional to F) — scaled x4 to one forward, x2 to one
     # CFG step.  32 threads: more threads made the oracle slower on the 256-core host (363 s per full
     # forward with 256 threads in an earlier run).
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "t2v":
         from oracle import torch_ref
         gold = torch.load(os.path.join(ROOT, "tests", "golden", "unet_t2v_full.pt"), map_location="cpu",
                           weights_only=False)
@@ -303,7 +404,8 @@ def main():
         res["cpu_baseline"] = {"value": round(1.0 / (2 * fwd_s), 5), "unit": "steps/s", "cores": cores,
                                "kind": "port",
                                "sample": "oracle (oracle/torch_ref.py, fp32) full-size UNet on a 4-frame latent "
-                                         f"[1,4,4,32,56]: {cpu_s:.1f} s, x4 frames x2 CFG branches per step"}
+                                         f"[1,4,4,32,56]: {cpu_s:.1f} s, x4 frames x2 CFG branches per step "
+                                         "(extrapolated: 5-D GroupNorm / temporal attention do not scale exactly with F)"}
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

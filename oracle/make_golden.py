@@ -172,6 +172,105 @@ def make_vcomposer(R):
 
 
 @torch.no_grad()
+def _no_cuda():
+    """context: the reference hard-codes .cuda() in a few places (unet_i2vgen.py:284, unet_sr600.py:38)"""
+    import contextlib
+
+    @contextlib.contextmanager
+    def cm():
+        _cuda = torch.Tensor.cuda
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        try:
+            yield
+        finally:
+            torch.Tensor.cuda = _cuda
+    return cm()
+
+
+def make_odd(R):
+    """BASELINE configs 3-5 shapes at reduced width: the 720p latent grid of the sr600 / i2vgen stages (H = 90:
+    90 -> 45 -> 23 -> 12 rows through pad-(2,1) downsamples and cropped upsamples, 14400-token spatial attention,
+    S % 64 != 0 at the lower levels; 88 x 160 with a 145-token context for i2vgen) and an odd-sized VAE frame."""
+    SR = dict(UNET_TINY, dim_mult=[1, 2, 4, 4], use_scale_shift_norm=True, inpainting=True)
+    SR.pop("use_fps_condition", None)
+    sr = R["MODEL"].build(dict(type="UNetSD_SR600", **SR)).eval()
+    shapes = torch_ref.shapes_of(sr)
+    sr.load_state_dict(torch_ref.synth_state_dict(shapes, seed=13), strict=True)
+    g = torch.Generator("cpu").manual_seed(19)
+    x = torch.randn(1, 4, 4, 90, 160, generator=g)
+    y = torch.randn(1, 77, 1024, generator=g)
+    t = torch.tensor([699])
+    with _no_cuda(), torch.no_grad():
+        out = sr(x.clone(), t, y)
+    torch.save(dict(cfg=SR, seed=13, shapes=shapes, x=x, t=t, y=y, out=out), os.path.join(GOLD, "unet_sr600_odd.pt"))
+    print("unet_sr600_odd", tuple(out.shape), float(out.std()))
+
+    ref = R["MODEL"].build(dict(type="UNetSD_I2VGen", **I2V_TINY)).eval()
+    shapes = torch_ref.shapes_of(ref)
+    ref.load_state_dict(torch_ref.synth_state_dict(shapes, seed=14), strict=True)
+    g = torch.Generator("cpu").manual_seed(23)
+    x = torch.randn(1, 4, 4, 88, 160, generator=g)
+    y = torch.randn(1, 77, 1024, generator=g)
+    image = torch.randn(1, 1, 1024, generator=g)
+    local_image = torch.randn(1, 4, 88, 160, generator=g)
+    fps = torch.tensor([8])
+    t = torch.tensor([981])
+    with _no_cuda(), torch.no_grad():
+        out = ref(x, t, y=y, image=image, local_image=local_image, fps=fps)
+    torch.save(dict(cfg=I2V_TINY, seed=14, shapes=shapes, x=x, t=t, y=y, image=image, local_image=local_image,
+                    fps=fps, out=out), os.path.join(GOLD, "unet_i2vgen_odd.pt"))
+    print("unet_i2vgen_odd", tuple(out.shape), float(out.std()))
+
+    vae = R["AUTO_ENCODER"].build(dict(type="AutoencoderKL", ddconfig=VAE_TINY, embed_dim=4)).eval()
+    vshapes = torch_ref.shapes_of(vae)
+    vae.load_state_dict(torch_ref.synth_state_dict(vshapes, seed=15), strict=True)
+    g = torch.Generator("cpu").manual_seed(29)
+    z = torch.randn(1, 4, 15, 25, generator=g)             # 375 latent pixels: the attention's 64-column padding
+    img = torch.randn(1, 3, 120, 200, generator=g)
+    with torch.no_grad():
+        dec = vae.decode(z)
+        mom = vae.encode(img).parameters
+    torch.save(dict(ddconfig=VAE_TINY, seed=15, shapes=vshapes, z=z, img=img, dec=dec, moments=mom),
+               os.path.join(GOLD, "vae_odd.pt"))
+    print("vae_odd", tuple(dec.shape), tuple(mom.shape))
+
+
+def make_yardstick(R, full):
+    """How far the reference's OWN mixed-precision arithmetic (amp.autocast, the mode its engines run:
+    `use_fp16: True`, inference_text2video_entrance.py:197) lands from its fp32 forward on the fixtures' inputs —
+    the yardstick the 16-bit HIP path is held to (tests/test_gpu_model.py)."""
+    import json
+    res = {}
+
+    def measure(name, model, ref, call):
+        for dn, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+            with torch.no_grad(), torch.autocast("cpu", dtype=dt):
+                o = call(model)
+            res[f"{name}/{dn}"] = float((o.float() - ref).norm() / ref.norm())
+            print(name, dn, res[f"{name}/{dn}"], flush=True)
+
+    g = torch.load(os.path.join(GOLD, "unet_tiny.pt"), weights_only=False)
+    m = R["MODEL"].build(dict(type="UNetSD_T2VBase", **g["cfg"])).eval()
+    m.load_state_dict(torch_ref.synth_state_dict(g["shapes"], seed=g["seed"]), strict=True)
+    measure("unet_tiny", m, g["out"].float(), lambda mm: mm(g["x"], g["t"], y=g["y"]))
+    g = torch.load(os.path.join(GOLD, "vae_tiny.pt"), weights_only=False)
+    v = R["AUTO_ENCODER"].build(dict(type="AutoencoderKL", ddconfig=g["ddconfig"], embed_dim=4)).eval()
+    v.load_state_dict(torch_ref.synth_state_dict(g["shapes"], seed=g["seed"]), strict=True)
+    measure("vae_tiny_decode", v, g["dec"].float(), lambda vv: vv.decode(g["z"]))
+    if full:
+        g = torch.load(os.path.join(GOLD, "unet_t2v_full.pt"), weights_only=False)
+        m = R["MODEL"].build(dict(type="UNetSD_T2VBase", **g["cfg"])).eval()
+        m.load_state_dict(torch_ref.synth_state_dict(g["shapes"], seed=g["seed"]), strict=True)
+        gen = torch.Generator("cpu").manual_seed(g["input_seed"])
+        x = torch.randn(1, 4, 16, 32, 56, generator=gen)
+        y = torch.randn(1, 77, 1024, generator=gen)
+        measure("unet_t2v_full", m, g["out"].float(), lambda mm: mm(x, g["t"], y=y))
+    path = os.path.join(GOLD, "autocast_yardstick.json")
+    old = json.load(open(path)) if os.path.exists(path) else {}
+    old.update(res)
+    json.dump(old, open(path, "w"), indent=1)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--full", action="store_true")
@@ -193,6 +292,12 @@ def main():
         return
     if args.only == "histogram":
         make_histogram(R)
+        return
+    if args.only == "odd":
+        make_odd(R)
+        return
+    if args.only == "yardstick":
+        make_yardstick(R, args.full)
         return
     torch.manual_seed(0)
 
@@ -280,6 +385,7 @@ def main():
     make_tft2v(R)
     make_vcomposer(R)
     make_histogram(R)
+    make_odd(R)
 
     # ---- tiny VAE ------------------------------------------------------------------------------
     vae = R["AUTO_ENCODER"].build(dict(type="AutoencoderKL", ddconfig=VAE_TINY, embed_dim=4)).eval()

@@ -307,3 +307,17 @@ def test_histogram_per_frame_context_oracle_and_host_logic_vs_reference_golden(e
     a, b = m.forward_units(g["x"], g["t"], [kw1, kw2])       # per-frame contexts of two units stacked frame-major
     assert rel_l2(a, out) < 3e-3 and rel_l2(b, m(g["x"], g["t"], **kw2)) < 3e-3
     assert abs(rel_l2(a, g["out"]) - rel_l2(out, g["out"])) < 5e-4
+
+
+def test_vae_attention_query_blocks(emu_backend):
+    """The mid-block attention forms its scores per block of queries (720p latents: hw x hw would not fit);
+    several ragged blocks must give the single-block result."""
+    from vgen_amd.vae import AutoencoderKL
+    g = gold("vae_tiny.pt")
+    v = AutoencoderKL(ddconfig=g["ddconfig"], embed_dim=4, compute_dtype="fp16").eval()
+    v.load_state_dict(torch_ref.synth_state_dict(g["shapes"], seed=g["seed"]), strict=True)
+    one = v.decode(g["z"])
+    v._attn_qb = 12                                        # hw = 32 -> blocks of 12, 12, 8 queries
+    assert rel_l2(v.decode(g["z"]), one) < 1e-6
+    with pytest.raises(NotImplementedError):
+        AutoencoderKL(ddconfig=g["ddconfig"], embed_dim=8)

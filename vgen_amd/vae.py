@@ -164,12 +164,17 @@ class AutoencoderKL(nn.Module):
         self.encoder = _EncoderP(**ddconfig)
         self.decoder = _DecoderP(**ddconfig)
         assert ddconfig["double_z"]
+        if embed_dim != ddconfig["z_channels"]:
+            # quant_conv / post_quant_conv and DiagonalGaussianDistribution are laid out for 2*z_channels moments
+            # (every config of the reference uses embed_dim == z_channels == 4, tools/modules/config.py:118-135)
+            raise NotImplementedError(f"AutoencoderKL: embed_dim ({embed_dim}) != z_channels ({ddconfig['z_channels']})")
         self.zc = ddconfig["z_channels"]
         self.quant_conv = nn.Conv2d(2 * ddconfig["z_channels"], 2 * embed_dim, 1)
         self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
         self.embed_dim = embed_dim
         self.compute_dtype = ops.sixteen(compute_dtype)
         self._packed = None
+        self._attn_qb = None          # query-block override of the mid attention (tests force several blocks)
         if pretrained is not None:
             self.init_from_ckpt(pretrained, ignore_keys=ignore_keys)
 
@@ -270,15 +275,23 @@ class AutoencoderKL(nn.Module):
         qk = be.tapgemm(TapGemm(A=a, W=Wqk, M=M, N=2 * c, C1=c, bias=bqk, out_dtype=dt))
         hwp = ((hw + 63) // 64) * 64
         o = torch.empty((M, c), dtype=dt, device=x.device)
+        # scores are formed per block of QB queries: S [QB, hw] fp32 stays <= 64 MiB (a whole 90x160 latent frame
+        # of the 720p configs would need 829 MB for hw x hw; 32x56 frames fit in one block)
+        QB = min(hw, self._attn_qb or max(256, ((16 << 20) // hwp) // 256 * 256))
+        S = torch.empty((QB, hw), dtype=torch.float32, device=x.device)
+        Pm = torch.zeros((QB, hwp), dtype=dt, device=x.device)          # pad columns stay zero
+        vt = torch.zeros((c, hwp), dtype=dt, device=x.device)
+        scale = float(int(c) ** (-0.5))
         for i in range(n):
             rows = slice(i * hw, (i + 1) * hw)
             # V^T[c, p] = sum_ci Wv[c, ci] a[p, ci]  (bias folded after PV: softmax rows sum to 1)
-            vt = torch.zeros((c, hwp), dtype=dt, device=x.device)
             be.tapgemm(TapGemm(A=P["v"], W=a[rows], M=c, N=hw, C1=c, out_dtype=dt, out=vt))
-            S = be.tapgemm(TapGemm(A=qk[rows, :c], W=qk[rows, c:], M=hw, N=hw, C1=c))
-            Pm = torch.zeros((hw, hwp), dtype=dt, device=x.device)
-            be.softmax_rows(S, hw, float(int(c) ** (-0.5)), dt, out=Pm)
-            be.tapgemm(TapGemm(A=Pm, W=vt, M=hw, N=c, C1=hwp, bias=P["vb"], out_dtype=dt, out=o[rows]))
+            for q0 in range(0, hw, QB):
+                qb = min(QB, hw - q0)
+                qr = slice(i * hw + q0, i * hw + q0 + qb)
+                be.tapgemm(TapGemm(A=qk[qr, :c], W=qk[rows, c:], M=qb, N=hw, C1=c, out=S[:qb]))
+                be.softmax_rows(S[:qb], hw, scale, dt, out=Pm[:qb])
+                be.tapgemm(TapGemm(A=Pm[:qb], W=vt, M=qb, N=c, C1=hwp, bias=P["vb"], out_dtype=dt, out=o[qr]))
         Wo, bo = P["o"]
         return be.tapgemm(TapGemm(A=o, W=Wo, M=M, N=c, C1=c, bias=bo, residual=x))
 
