@@ -184,9 +184,10 @@ def main():
     C, F, H, W = cfg["latent"]
     G = cfg["G"]
     model = build_model(args.config, dev, args.dtype)
-    for p in model.parameters():                      # fp32 masters are not needed for sampling
-        p.data = torch.empty(0, device=dev)
-    torch.cuda.empty_cache()
+    if args.config == "t2v":                          # fp32 masters are not needed for sampling (the variants'
+        for p in model.parameters():                  # condition stems run on theirs)
+            p.data = torch.empty(0, device=dev)
+        torch.cuda.empty_cache()
 
     diff = DiffusionDDIM(**DDIM)
     diff.rng_parity = False

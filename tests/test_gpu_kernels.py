@@ -103,3 +103,56 @@ def test_frames_u8_bit_exact(hip_backend):
     xp = torch.randn(100, 8, generator=gen)                    # strided rows (ldx > C)
     out = hip_backend.frames_u8(xp.to(DEV)[:, :3], mean.to(DEV), std.to(DEV))
     assert torch.equal(out.cpu(), kc.EMU.frames_u8(xp[:, :3], mean, std))
+
+
+def test_linear_f32_and_fp32_sinusoid(hip_backend):
+    """vgen_linear_f32 vs float64, and its contract that an output element does not depend on how many rows are
+    evaluated together or where the row sits (a session's time-embedding table row == the per-step evaluation)."""
+    g = torch.Generator().manual_seed(11)
+    for K, N in ((320, 1280), (1280, 20160), (64, 100)):
+        W = torch.randn(N, K, generator=g) / K ** 0.5
+        b = torch.randn(N, generator=g)
+        x = torch.randn(19, K, generator=g)
+        add = torch.randn(19, N, generator=g)
+        for act in (0, 1):
+            out = hip_backend.linear_f32(x.to(DEV), W.to(DEV), b.to(DEV), act_in=act, add=add.to(DEV)).cpu()
+            v = x.double()
+            v = v * torch.sigmoid(v) if act else v
+            ref = (v @ W.double().t() + b.double() + add.double()).float()
+            assert float((out - ref).norm() / ref.norm()) < 2e-6
+            one = hip_backend.linear_f32(x[5:6].to(DEV), W.to(DEV), b.to(DEV), act_in=act).cpu()
+            for n, pos in ((2, 1), (8, 7), (9, 8), (1000, 601)):
+                xs = torch.randn(n, K, generator=g)
+                xs[pos] = x[5]
+                o = hip_backend.linear_f32(xs.to(DEV), W.to(DEV), b.to(DEV), act_in=act).cpu()
+                assert torch.equal(o[pos], one[0]), (K, N, act, n, pos)
+    t = torch.tensor([0.0, 1.0, 601.0, 999.0, 12.5])
+    s = hip_backend.timestep_embedding(t.to(DEV), 320, torch.float32).cpu()
+    assert s.dtype == torch.float32 and float((s - kc.EMU.timestep_embedding(t, 320, torch.float32)).abs().max()) < 2e-4
+
+
+def test_ddim_update_units_bit_exact(hip_backend):
+    """vgen_cfg_ddim_step_units: table-indexed coefficients, x_t read from the unit slots, x_{t-1} replicated into
+    them (in place) — the same bits as the plain kernel."""
+    g = torch.Generator().manual_seed(3)
+    G, B, Cs, Cl, F, H, W = 2, 3, 6, 4, 2, 5, 7
+    xu = torch.randn(G * B, Cs, F, H, W, generator=g)
+    xt = torch.randn(B, Cl, F, H, W, generator=g)
+    xu.view(G, B, Cs, F, H, W)[:, :, :Cl] = xt
+    y, u, nz = (torch.randn(B, Cl, F, H, W, generator=g) for _ in range(3))
+    tab = torch.rand(50, 7, generator=g) * 0.8 + 0.1
+    tab[:, 5] *= 0.3
+    tidx = torch.tensor([7, 0, 49])
+    ref, ref0 = kc.EMU.cfg_ddim_step(xt, y, u, nz, tab[tidx].contiguous(), 9.0, True, 1, True)
+    xud = xu.to(DEV)
+    o = torch.empty_like(xt, device=DEV)
+    o0 = torch.empty_like(xt, device=DEV)
+    hip_backend.ddim_update_units(xud, G, B, Cl, y.to(DEV), u.to(DEV), nz.to(DEV), tab.to(DEV), tidx.to(DEV), 9.0, True,
+                                  1, o, o0, replicate=True)
+    got, got0 = hip_backend.cfg_ddim_step(xt.to(DEV), y.to(DEV), u.to(DEV), nz.to(DEV), tab[tidx].contiguous().to(DEV),
+                                          9.0, True, 1, True)
+    assert torch.equal(o, got) and torch.equal(o0, got0)
+    assert float((o.cpu() - ref).abs().max()) < 1e-5
+    v = xud.view(G, B, Cs, F, H, W).cpu()
+    assert torch.equal(v[0, :, :Cl], o.cpu()) and torch.equal(v[1, :, :Cl], o.cpu())
+    assert torch.equal(v[:, :, Cl:], xu.view(G, B, Cs, F, H, W)[:, :, Cl:])          # stem channels untouched

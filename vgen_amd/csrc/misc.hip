@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
                                                          const float* __restrict__ bias, int N, int act_in,
                                                          const float* __restrict__ add,
                                                          float* __restrict__ out) {
+#pragma clang fp contract(off)   // the k-loop below spells out its FMAs: same rounding for every row slot r
   extern __shared__ __attribute__((aligned(16))) float lin_xs[];   // [LIN_R][K]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r0 = blockIdx.y * LIN_R;
@@ -75,7 +76,9 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
 #pragma unroll
     for (int r = 0; r < LIN_R; ++r) {
       const f32x4 v = *(const f32x4*)(lin_xs + r * K + k);
-      acc[r] += (v.x * w.x + v.y * w.y) + (v.z * w.z + v.w * w.w);
+      // explicit fused multiply-adds in a fixed order (left to the compiler, the contraction pattern differed
+      // between the unrolled row slots: a table row and the per-step row of the same timestep were 1 ulp apart)
+      acc[r] = __builtin_fmaf(v.w, w.w, __builtin_fmaf(v.z, w.z, __builtin_fmaf(v.y, w.y, __builtin_fmaf(v.x, w.x, acc[r]))));
     }
   }
 #pragma unroll
