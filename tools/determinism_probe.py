@@ -1,5 +1,9 @@
 """GPU probe: run the full-size t2v UNet forward several times on identical inputs; report bitwise
-differences / non-finite outputs (a race or an uninitialised read shows up as run-to-run drift)."""
+differences / non-finite outputs (a race or an uninitialised read shows up as run-to-run drift), and locate the
+FIRST kernel launch whose output differs between two runs although its inputs were identical.
+
+    python tools/determinism_probe.py [runs]            VGEN_TEMPORAL_MINB=2 selects the min-2-blocks temporal kernel
+"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -9,6 +13,7 @@ from vgen_amd.unet import UNetSD_T2VBase
 
 dev = torch.device("cuda", 0)
 ops.set_backend(None)
+be = ops.backend()
 with torch.device(dev):
     m = UNetSD_T2VBase(**UNET_T2V, compute_dtype="bf16")
 m.eval(); randomize_(m, 0); m.pack()
@@ -17,20 +22,56 @@ x = torch.randn(2, 4, 16, 32, 56, generator=g, device=dev)
 y = torch.randn(2, 77, 1024, generator=g, device=dev)
 t = torch.tensor([981, 981], device=dev)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
+
+trace = None
+
+
+def sig(tn):
+    v = tn.detach()
+    if v.dtype in (torch.bfloat16, torch.float16):
+        v = v.contiguous().view(torch.int16)
+    elif v.dtype == torch.float32:
+        v = v.contiguous().view(torch.int32)
+    v = v.to(torch.int64)
+    return (int(v.sum()), int((v * (torch.arange(v.numel(), device=v.device).view(v.shape) % 8191 + 1)).sum()))
+
+
+def wrap(name, fn, ins, outs):
+    def f(*a, **k):
+        r = fn(*a, **k)
+        if trace is not None:
+            trace.append((name, tuple(sig(z) for z in ins(*a, **k) if z is not None), tuple(sig(z) for z in outs(r) if z is not None)))
+        return r
+    return f
+
+
+be.attention = wrap("attention", be.attention, lambda g_: (g_.q,), lambda r: (r,))
+be.tapgemm = wrap("tapgemm", be.tapgemm, lambda g_: (g_.A, g_.residual), lambda r: (r, getattr(r, "vgen_cs", None)))
+be.groupnorm = wrap("groupnorm", be.groupnorm, lambda *a, **k: (a[0], a[1]), lambda r: r)
+be.layernorm = wrap("layernorm", be.layernorm, lambda *a, **k: (a[0],), lambda r: (r,))
+
 ref = None
+ref_trace = None
 bad = 0
 for i in range(n):
     # poison the caching allocator's free blocks so that reads of never-written memory differ run to run
     junk = torch.full((64 * 1024 * 1024,), float("nan") if i % 2 else 1e30, device=dev); del junk
+    trace = []
     out = m(x, t, y=y)
     torch.cuda.synchronize()
     fin = bool(torch.isfinite(out).all())
     if ref is None:
         ref = out.clone()
-        print("run 0 finite", fin, "absmax", float(out.abs().max()))
+        ref_trace = trace
+        print("run 0 finite", fin, "absmax", float(out.abs().max()), "launches traced", len(trace))
     else:
         d = (out - ref)
         same = torch.equal(out, ref)
         bad += (not same) or (not fin)
         print("run", i, "finite", fin, "bitwise equal", same, "max|diff|", float(d.abs().nan_to_num(nan=1e38).max()))
+        if not same:
+            for j, (a, b) in enumerate(zip(ref_trace, trace)):
+                if a != b:
+                    print("   first differing launch #%d: %s  inputs equal: %s  outputs equal: %s" % (j, a[0], a[1] == b[1], a[2] == b[2]))
+                    break
 print("RESULT", "DRIFT" if bad else "deterministic")

@@ -22,6 +22,7 @@
 //                    2 MFMA 16x16x32, the softmax is in-lane + 2 shuffles, and P V uses the
 //                    K=16 MFMA (16x16x16) whose B layout again equals S^T's C/D layout.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -231,11 +232,16 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(const vgen_attn_args p, i
 }
 
 // =========================================================================================
-// NOTE: keep the default launch bounds here.  `__launch_bounds__(256, 2)` (which makes hipcc keep the MFMA
-// accumulators in VGPRs, a 20 % win for flash_kernel) gave run-to-run different outputs for this kernel
-// on the full-size UNet (tools/determinism_probe.py) although every kernel-level test passed.
-template <typename T>
-__global__ __launch_bounds__(256) void temporal_kernel(const vgen_attn_args p, int64_t npairs) {
+// History: r01 saw this kernel drift from run to run under `__launch_bounds__(256, 2)` and kept the default bounds
+// without a cause.  Root cause (r02, tools/determinism_probe.py located the first differing launch, the ISA showed
+// it): BF16::pack2 was an inline-asm `v_cvt_pk_bf16_f32`; with min-2-blocks bounds the MFMA results stay in VGPRs
+// and the asm consumed them straight after `v_mfma_f32_16x16x16_bf16` — the compiler's hazard recogniser does not
+// look inside asm blocks, so none of the required wait states were inserted and the conversion read the registers
+// before the matrix pipe had written them (stale / NaN values).  With AGPR accumulators the v_accvgpr_read in
+// between hid the latency.  pack2 is now a vector conversion the compiler lowers (common.h); both bounds are
+// bit-reproducible (profiles/r02_temporal_minb2_*.log).
+template <typename T, int MINB>
+__global__ __launch_bounds__(256, MINB) void temporal_kernel(const vgen_attn_args p, int64_t npairs) {
   constexpr int VS = 72;
   __shared__ __attribute__((aligned(16))) uint16_t sV[4][16 * VS];  // per wave: [key][64 d + pad]
 
@@ -338,10 +344,18 @@ extern "C" int vgen_attention(const vgen_attn_args* args, void* stream) {
     const int64_t npairs = a.nbatch * a.heads;
     const int64_t grid = (npairs + 3) / 4;
     VGEN_REQUIRE(grid < (1LL << 31), "attention: grid too large");
-    if (a.dtype == VGEN_BF16)
-      hipLaunchKernelGGL(temporal_kernel<BF16>, dim3((unsigned)grid), dim3(256), 0, s, a, npairs);
+    // min-2-blocks launch bounds keep the MFMA results in VGPRs (no v_accvgpr round trip): 34.62 vs 34.72 ms / step.
+    // tuning / diagnosis switch (not part of the ABI): VGEN_TEMPORAL_MINB=1 runs the AGPR instantiation
+    static const int minb = getenv("VGEN_TEMPORAL_MINB") ? atoi(getenv("VGEN_TEMPORAL_MINB")) : 2;
+    if (minb == 2) {
+      if (a.dtype == VGEN_BF16)
+        hipLaunchKernelGGL((temporal_kernel<BF16, 2>), dim3((unsigned)grid), dim3(256), 0, s, a, npairs);
+      else
+        hipLaunchKernelGGL((temporal_kernel<F16, 2>), dim3((unsigned)grid), dim3(256), 0, s, a, npairs);
+    } else if (a.dtype == VGEN_BF16)
+      hipLaunchKernelGGL((temporal_kernel<BF16, 1>), dim3((unsigned)grid), dim3(256), 0, s, a, npairs);
     else
-      hipLaunchKernelGGL(temporal_kernel<F16>, dim3((unsigned)grid), dim3(256), 0, s, a, npairs);
+      hipLaunchKernelGGL((temporal_kernel<F16, 1>), dim3((unsigned)grid), dim3(256), 0, s, a, npairs);
     return vgen_check_launch("attention(temporal)");
   }
   const int qtiles = (a.nq + 127) / 128;

@@ -10,6 +10,7 @@
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
@@ -32,10 +33,14 @@ struct BF16 {
   // two fp32 -> packed bf16 in ONE instruction (gfx950 v_cvt_pk_bf16_f32, round-to-nearest-even);
   // the bit-twiddling from_f32() above costs ~6 VALU ops per value and made the attention
   // softmax VALU-bound (SQ_ACTIVE_INST_VALU = 43 % of wave cycles at 2 waves / SIMD).
+  // Written as a vector conversion the COMPILER lowers to that instruction — not as inline asm: the hazard
+  // recogniser does not look inside asm blocks, so an asm v_cvt_pk_bf16_f32 that consumed an MFMA result straight
+  // from VGPRs was issued without the required wait states and read the registers before the matrix pipe had
+  // written them (r01's "temporal_kernel drifts run to run under __launch_bounds__(256, 2)": with accumulators
+  // in AGPRs the v_accvgpr_read in between happened to cover the latency).
   static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-    uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
-    return r;
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
   }
   static __device__ __forceinline__ f32x4 mfma32(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8_t, a),

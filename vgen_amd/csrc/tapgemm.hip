@@ -60,7 +60,12 @@ struct RowState {
 
 constexpr int INVALID = -(1 << 24);
 
-__device__ u32x4 g_zero16 = {0u, 0u, 0u, 0u};   // source of padding / out-of-range rows
+// Source of padding / out-of-range rows: a zero REGION long enough for a pointer to walk a whole K extent through it
+// (K * 2 bytes <= 64 KiB - 128, checked on the host), so every DMA source pointer advances by the same ROW_BYTES
+// per K-tile whether its row is live or not — no per-piece increment registers (7 VGPRs on the dual shape, which
+// sat at 256 VGPRs with 3 spills).
+constexpr int ZERO_BYTES = 65536;
+__device__ __attribute__((aligned(128))) unsigned char g_zeros[ZERO_BYTES];
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -186,8 +191,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   // per K-tile against 32 MFMAs — the loop was issue-bound, not memory- or MFMA-bound.)
   constexpr int NP = LPT + (RBT > 0 ? 1 : 0);
   const char* pc[NP];
-  int inc[NP];
-  const char* const zline = (const char*)&g_zero16;
+  const char* const zline = (const char*)g_zeros;
   const int src_cb = (ld_c ^ swz_key<CPR>(ld_r)) * 16;   // byte offset of this lane's source chunk
   const int wave_row0 = wave * RPI;              // first tile row written by this wave's DMA (+RPP*i)
   int kt_next = kt_begin;                        // K-tile the pointers currently describe
@@ -221,17 +225,15 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
           ok = rs[i].base >= 0;
           row = rs[i].base;
         }
-        pc[i] = ok ? (const char*)(A + row * p.lda + cch * BK) + src_cb : zline;
-        inc[i] = ok ? ROW_BYTES : 0;
+        pc[i] = (ok ? (const char*)(A + row * p.lda + cch * BK) : zline) + src_cb;
       }
     } else {
       left = KT - kt + 1;
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
         const bool ok = (mvalid >> i) & 1u;
-        pc[i] = ok ? (const char*)(A2 + (int64_t)((unsigned)m0 + ld_r + RPP * i) * p.lda2 + (kt - T1) * BK) + src_cb
-                   : zline;
-        inc[i] = ok ? ROW_BYTES : 0;
+        pc[i] = (ok ? (const char*)(A2 + (int64_t)((unsigned)m0 + ld_r + RPP * i) * p.lda2 + (kt - T1) * BK) : zline) +
+                src_cb;
       }
     }
   };
@@ -240,8 +242,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   for (int i = 0; i < NP - RA; ++i) {
     const int n = n0 + ld_r + RPP * i;
     const bool ok = n < p.N;
-    pc[RA + i] = ok ? (const char*)(W + (int64_t)n * ldw + (int64_t)kt_begin * BK) + src_cb : zline;
-    inc[RA + i] = ok ? ROW_BYTES : 0;
+    pc[RA + i] = (ok ? (const char*)(W + (int64_t)n * ldw + (int64_t)kt_begin * BK) : zline) + src_cb;
   }
   auto advance = [&]() __attribute__((always_inline)) {   // pointers -> next K-tile
     ++kt_next;
@@ -249,10 +250,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
       if (kt_next < KT) gather_a(kt_next);
     } else {
 #pragma unroll
-      for (int i = 0; i < RA; ++i) pc[i] += inc[i];
+      for (int i = 0; i < RA; ++i) pc[i] += ROW_BYTES;
     }
 #pragma unroll
-    for (int i = RA; i < NP; ++i) pc[i] += inc[i];
+    for (int i = RA; i < NP; ++i) pc[i] += ROW_BYTES;
   };
   // LDS destination (wave-uniform) of piece j in `stage`
   auto piece_dst = [&](int stage, int j) __attribute__((always_inline)) -> unsigned char* {
@@ -266,11 +267,34 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
     advance();
   };
 
+  // Accumulators start from the fp32 RESIDUAL tile instead of zero: the residual loads (one HBM / MALL round trip
+  // per row fragment, 4-8 of them back to back in the old epilogue because hoisting them all would need > 100
+  // VGPRs) are issued here, land straight in the accumulator registers while the first operand tiles are in
+  // flight, and the epilogue is left with arithmetic and stores only.  VMEM loads return in order, so the counted
+  // vmcnt that publishes K-tile 0 also covers them.  (Not with split-K — the reducer adds the residual — nor with
+  // GEGLU, whose residual is added after the gate.)
+  const bool geglu = p.epilogue == VGEN_EPI_GEGLU;
+  const int n_out = geglu ? p.N / 2 : p.N;
+  const bool vec = ((n_out & 3) == 0) && ((p.ldo & 3) == 0) &&
+                   (p.residual == nullptr || (p.ldr & 3) == 0) &&
+                   (p.rowbias == nullptr || (p.rowbias_ld & 3) == 0);
+  const bool res_folded = p.residual != nullptr && splitk == 1 && vec && !geglu;
   f32x4 acc[NF][MF];
 #pragma unroll
   for (int ni = 0; ni < NF; ++ni)
 #pragma unroll
     for (int mi = 0; mi < MF; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (res_folded) {
+#pragma unroll
+    for (int mi = 0; mi < MF; ++mi) {
+      const int64_t m = m0 + wm * WTM + mi * 16 + lr;
+#pragma unroll
+      for (int ni = 0; ni < NF; ++ni) {
+        const int n = n0 + wn * WTN + ni * 16 + lq * 4;
+        if (m < p.M && n < p.N) acc[ni][mi] = *(const f32x4*)(p.residual + m * p.ldr + n);
+      }
+    }
+  }
 
   // fragment read offsets: row (frag*16 + lr), chunk (ks*4 + lq) ^ key(lr)
   const int rd_row = lr * ROW_BYTES;
@@ -449,11 +473,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   }
 
   // ---- epilogue -------------------------------------------------------------------------
-  const bool geglu = p.epilogue == VGEN_EPI_GEGLU;
-  const int n_out = geglu ? p.N / 2 : p.N;
-  const bool vec = ((n_out & 3) == 0) && ((p.ldo & 3) == 0) &&
-                   (p.residual == nullptr || (p.ldr & 3) == 0) &&
-                   (p.rowbias == nullptr || (p.rowbias_ld & 3) == 0);
   float* const of = (float*)p.out;
   uint16_t* const oh = (uint16_t*)p.out;
 
@@ -528,7 +547,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
         if (vec) {
           v += bv[ni];
           if (rbp) v += *(const f32x4*)(rbp + n);
-          if (p.residual) v += *(const f32x4*)(p.residual + m * p.ldr + n);
+          if (p.residual && !res_folded) v += *(const f32x4*)(p.residual + m * p.ldr + n);
           if (do_cs) {
             cs_s[ni] += v;
             cs_q[ni] += v * v;
@@ -638,6 +657,11 @@ struct PlanEntry {
 };
 #include "tapgemm_plans.inc"
 
+// the active table: the compiled-in one, or whatever vgen_tapgemm_set_plans installed (tools/autotune_gemm.py
+// A/B-tests a candidate table inside one process before it is baked into tapgemm_plans.inc)
+PlanEntry* g_plans = nullptr;
+int g_nplans = -1;
+
 Plan make_plan(const vgen_tapgemm_args& a) {
   const bool geglu = a.epilogue == VGEN_EPI_GEGLU;
   const int KT = a.taps * (a.C1 / 64) + a.C2 / 64;
@@ -670,9 +694,13 @@ Plan make_plan(const vgen_tapgemm_args& a) {
   static const bool use_table = env_int("VGEN_TAPGEMM_TABLE", 1) != 0;
   if (use_table && force_shape < 0) {
     const int flags = (a.residual ? 1 : 0) | (a.rowbias ? 2 : 0) | (a.colstats ? 4 : 0);
-    for (const PlanEntry& e : kPlans) {
+    const PlanEntry* tab = g_nplans >= 0 ? g_plans : kPlans;
+    const int ntab = g_nplans >= 0 ? g_nplans : (int)(sizeof(kPlans) / sizeof(kPlans[0]));
+    for (int i = 0; i < ntab; ++i) {
+      const PlanEntry& e = tab[i];
       if (e.mode == a.mode && e.M == a.M && e.N == a.N && e.C1 == a.C1 && e.C2 == a.C2 && e.taps == a.taps &&
-          e.epilogue == a.epilogue && e.out_dtype == a.out_dtype && e.flags == flags && legal(e.shape, e.bn, e.splitk))
+          e.epilogue == a.epilogue && (e.out_dtype == VGEN_F32) == (a.out_dtype == VGEN_F32) && e.flags == flags &&
+          legal(e.shape, e.bn, e.splitk))   // out_dtype: fp32 vs 16-bit (bf16 and fp16 launches share an entry)
         return Plan{e.shape, e.bn, e.splitk};
     }
   }
@@ -777,6 +805,36 @@ int dispatch(const vgen_tapgemm_args& a, hipStream_t s) {
 
 }  // namespace
 
+extern "C" int vgen_tapgemm_query_plan(const vgen_tapgemm_args* args, int32_t* out3) {
+  if (!args || !out3 || args->N <= 0 || args->M <= 0 || args->C1 <= 0 || args->C1 % 64 || args->C2 % 64) return VGEN_E_BADARG;
+  const Plan pl = make_plan(*args);
+  out3[0] = pl.shape;
+  out3[1] = pl.bn;
+  out3[2] = pl.splitk;
+  return 0;
+}
+
+extern "C" int vgen_tapgemm_set_plans(const int64_t* rows, int32_t n) {
+  if (n < 0) {            // back to the compiled-in table
+    free(g_plans);
+    g_plans = nullptr;
+    g_nplans = -1;
+    return 0;
+  }
+  if (n > 0 && !rows) return VGEN_E_BADARG;
+  PlanEntry* t = (PlanEntry*)malloc(sizeof(PlanEntry) * (n > 0 ? n : 1));
+  if (!t) return VGEN_E_BADARG;
+  for (int i = 0; i < n; ++i) {
+    const int64_t* r = rows + 12 * i;
+    t[i] = PlanEntry{(int)r[0], r[1], (int)r[2], (int)r[3], (int)r[4], (int)r[5], (int)r[6], (int)r[7], (int)r[8],
+                     (int)r[9], (int)r[10], (int)r[11]};
+  }
+  free(g_plans);
+  g_plans = t;
+  g_nplans = n;
+  return 0;
+}
+
 extern "C" size_t vgen_tapgemm_ws_bytes(const vgen_tapgemm_args* args) {
   if (!args || args->N <= 0 || args->M <= 0 || args->C1 <= 0 || args->C1 % 64 || args->C2 % 64) return 0;
   const int s = make_plan(*args).splitk;
@@ -827,6 +885,8 @@ extern "C" int vgen_tapgemm(const vgen_tapgemm_args* args, void* stream) {
       return VGEN_E_BADARG;
   }
   VGEN_REQUIRE(a.M + 256 < (1LL << 31), "tapgemm: M overflows int32 row index");
+  VGEN_REQUIRE(((int64_t)a.taps * a.C1 + a.C2) * 2 <= ZERO_BYTES - 128, "tapgemm: K = %lld too long (<= 32704)",
+               (long long)((int64_t)a.taps * a.C1 + a.C2));
   if (a.epilogue == VGEN_EPI_GEGLU) {
     VGEN_REQUIRE(a.N % 64 == 0 && a.rowbias == nullptr && (a.ldo % 4 == 0) &&
                      (a.residual == nullptr || a.ldr % 4 == 0),

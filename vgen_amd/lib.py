@@ -67,6 +67,8 @@ SYMBOLS = {
     "vgen_layernorm": (C.c_int, [_vp, _i64, _i32, _f32, _vp, _vp, _vp, _i32, _vp]),
     "vgen_tapgemm_ws_bytes": (_sz, [C.POINTER(TapGemmArgs)]),
     "vgen_tapgemm": (C.c_int, [C.POINTER(TapGemmArgs), _vp]),
+    "vgen_tapgemm_query_plan": (C.c_int, [C.POINTER(TapGemmArgs), _vp]),
+    "vgen_tapgemm_set_plans": (C.c_int, [_vp, _i32]),
     "vgen_attention": (C.c_int, [C.POINTER(AttnArgs), _vp]),
     "vgen_softmax_rows": (C.c_int, [_vp, _i64, _i32, _i64, _f32, _vp, _i64, _i32, _vp]),
     "vgen_act_cast": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),

@@ -225,8 +225,14 @@ class HipBackend:
         if need:
             ws = torch.empty(need // 4, dtype=torch.float32, device=A.device)
             a.ws, a.ws_bytes = ws.data_ptr(), need
-        with self._Prof("tapgemm", 2.0 * g.M * g.N * (g.taps * g.C1 + g.C2),
-                        (g.mode, g.M, g.N, g.taps * g.C1 + g.C2, g.epilogue, str(g.out_dtype))):
+        meta = (g.mode, g.M, g.N, g.taps * g.C1 + g.C2, g.epilogue, str(g.out_dtype))
+        if KERNEL_PROFILE is not None and PROFILE_PLANS:
+            # full launch signature of the plan table + the plan make_plan picks for it (tools/autotune_gemm.py)
+            pl = (C.c_int32 * 3)()
+            self.lib.vgen_tapgemm_query_plan(C.byref(a), pl)
+            flags = (1 if g.residual is not None else 0) | (2 if g.rowbias is not None else 0) | (4 if cs is not None else 0)
+            meta = meta + ((g.mode, g.M, g.N, g.C1, g.C2, g.taps, g.epilogue, _ENUM[g.out_dtype], flags), tuple(pl))
+        with self._Prof("tapgemm", 2.0 * g.M * g.N * (g.taps * g.C1 + g.C2), meta):
             rc = self.lib.vgen_tapgemm(C.byref(a), self._stream(A))
         _lib.check(rc, "vgen_tapgemm")
         if cs is not None:
@@ -410,6 +416,7 @@ _backend = None
 # bench.py sets this to a list to bracket every tap-GEMM launch with HIP events on the launch
 # stream (torch's current stream) and collect (name, start, stop, algorithmic FLOP) records.
 KERNEL_PROFILE = None
+PROFILE_PLANS = False      # tools/autotune_gemm.py: also record each tap-GEMM's table signature and chosen plan
 
 
 def backend():
