@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VGEN_ABI_VERSION 2
+#define VGEN_ABI_VERSION 3
 
 enum { VGEN_BF16 = 0, VGEN_F16 = 1, VGEN_F32 = 2 };
 
@@ -81,7 +81,12 @@ int vgen_groupnorm_cs(const float* x1, int32_t C1, const float* cs1,
                       void* y, void* raw, int32_t dtype,
                       float* ws, size_t ws_bytes, void* stream);
 
-/* LayerNorm over the last dim, fp32 in -> 16-bit out (eps 1e-5 in the reference).
+/* Token + positional embedding of the CLIP text tower (tools/modules/clip_embedder.py:155-156):
+ * out[r, :] = table[tokens[r], :] + pos[r % L, :], fp32; tokens int64 [rows], table [vocab, d], pos [L, d]. */
+int vgen_embed_tokens(const int64_t* tokens, int64_t rows, int32_t L, int32_t d, int32_t vocab,
+                      const float* table, const float* pos, float* out, void* stream);
+
+/* LayerNorm over the last dim, fp32 in -> 16-bit out, or fp32 out with dtype VGEN_F32 (eps 1e-5 in the reference).
  * Replaces nn.LayerNorm norm1/2/3 of BasicTransformerBlock (util.py:692-694,700-704).
  * x [M, d] fp32 (row stride d), d % 4 == 0, d <= 2048. */
 int vgen_layernorm(const float* x, int64_t M, int32_t d, float eps,
@@ -123,10 +128,11 @@ int vgen_layernorm(const float* x, int64_t M, int32_t d, float eps,
  *       [16 value rows | 16 gate rows] (packed index pn; value j <-> rows 32*(j/16)+j%16,
  *       gate j <-> +16), bias likewise; out[m, j] = v_value * gelu_erf(v_gate), j < N/2.
  *       (GEGLU.forward, util.py:712-714.)
+ *   epilogue == VGEN_EPI_GELU: out = gelu_erf(v) (no residual; open_clip's mlp c_fc -> nn.GELU).
  *   out is fp32 or 16-bit (out_dtype), row stride ldo.
  */
 enum { VGEN_TAP_LINEAR = 0, VGEN_TAP_CONV3X3 = 1, VGEN_TAP_TEMPORAL3 = 2 };
-enum { VGEN_EPI_NONE = 0, VGEN_EPI_GEGLU = 1 };
+enum { VGEN_EPI_NONE = 0, VGEN_EPI_GEGLU = 1, VGEN_EPI_GELU = 2 };
 
 typedef struct vgen_tapgemm_args {
   int64_t M;
@@ -209,6 +215,8 @@ typedef struct vgen_attn_args {
   int64_t v_rs, v_bo, v_bi;
   int64_t o_rs, o_bo, o_bi;
   float scale;
+  int32_t causal; /* 1: key j contributes to query i only if j <= i (nn.MultiheadAttention with open_clip's
+                     build_attention_mask, tools/modules/clip_embedder.py:157 `attn_mask=self.model.attn_mask`) */
 } vgen_attn_args;
 
 int vgen_attention(const vgen_attn_args* args, void* stream);

@@ -114,6 +114,8 @@ class EmuBackend:
             n_out = g.N
         if g.residual is not None:
             acc += g.residual[:, :n_out]
+        if g.epilogue == L.EPI_GELU:
+            acc = 0.5 * acc * (1.0 + torch.erf(acc * 0.7071067811865476))
         out = g.out
         if out is None:
             out = torch.empty((g.M, n_out), dtype=g.out_dtype)
@@ -138,7 +140,10 @@ class EmuBackend:
             return _strided(t, (no, ni, g.heads, n, 64), (bo, bi, 64, rs, 1)).float()
 
         q, k, v = seqs(g.q, g.q_s, g.nq), seqs(g.k, g.k_s, g.nk), seqs(g.v, g.v_s, g.nk)
-        w = torch.softmax(q @ k.transpose(-1, -2) * g.scale, dim=-1)
+        sc = q @ k.transpose(-1, -2) * g.scale
+        if getattr(g, "causal", False):
+            sc = sc.masked_fill(torch.ones(g.nq, g.nk, dtype=torch.bool).triu(1), float("-inf"))
+        w = torch.softmax(sc, dim=-1)
         o = w @ v
         rs, bo, bi = g.o_s
         _strided(g.out, (no, ni, g.heads, g.nq, 64), (bo, bi, 64, rs, 1)).copy_(o.to(g.out.dtype))
@@ -154,6 +159,10 @@ class EmuBackend:
     # -- small kernels ---------------------------------------------------------------------------
     def act_cast(self, x, act, dt):
         return (x * torch.sigmoid(x) if act == 1 else x).to(dt)
+
+    def embed_tokens(self, tokens, table, pos):
+        B, Lk = tokens.shape
+        return (table[tokens.clamp(0, table.shape[0] - 1)] + pos[None]).reshape(B * Lk, -1).contiguous()
 
     def linear_f32(self, x, W, b, act_in=0, add=None):
         # float64 accumulation, rounded once: the result of a row does not depend on how many rows are evaluated

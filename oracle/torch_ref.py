@@ -686,3 +686,35 @@ def lcm_sample_loop(ac, timesteps, noise, model, model_kwargs, guidance_scale, s
         den = c_out * x0 + c_skip * x
         x = a_prev.sqrt() * den + (1 - a_prev).sqrt() * step_noise[i] if i != len(timesteps) - 1 else den
     return x
+
+
+# ------------------------------------------------------------------------------------------------
+# OpenCLIP text tower (third-party `open_clip`, not vendored / not pinned by the reference: PARITY UNPINNED against
+# the package itself).  Restated from its published architecture around torch.nn.MultiheadAttention — the module
+# open_clip's ResidualAttentionBlock wraps — following the reference's call sequence
+# (tools/modules/clip_embedder.py:154-161 encode_with_transformer, :55-64 text_transformer_forward).
+def clip_text_forward(sd, tokens, heads, layer_idx=1, prefix="model."):
+    """tokens int64 [B, L] -> (x [B, L, width] after ln_final, xt [B, embed] = x[eot] @ text_projection)."""
+    import torch.nn.functional as F
+    g = lambda k: sd[prefix + k].float()
+    x = g("token_embedding.weight")[tokens] + g("positional_embedding")             # :155-156
+    L = tokens.shape[1]
+    mask = torch.full((L, L), float("-inf")).triu_(1)                                # open_clip build_attention_mask
+    nl = 1 + max(int(k.split(".")[3]) for k in sd if k.startswith(prefix + "transformer.resblocks."))
+    x = x.permute(1, 0, 2)                                                           # NLD -> LND (:157)
+    d = x.shape[-1]
+    for i in range(nl - layer_idx):                                                  # penultimate: skip the last block
+        p = f"transformer.resblocks.{i}."
+        n = F.layer_norm(x, (d,), g(p + "ln_1.weight"), g(p + "ln_1.bias"), 1e-5)
+        a, _ = F.multi_head_attention_forward(n, n, n, d, heads, g(p + "attn.in_proj_weight"), g(p + "attn.in_proj_bias"),
+                                              None, None, False, 0.0, g(p + "attn.out_proj.weight"),
+                                              g(p + "attn.out_proj.bias"), training=False, need_weights=False,
+                                              attn_mask=mask)
+        x = x + a
+        n = F.layer_norm(x, (d,), g(p + "ln_2.weight"), g(p + "ln_2.bias"), 1e-5)
+        h = F.gelu(F.linear(n, g(p + "mlp.c_fc.weight"), g(p + "mlp.c_fc.bias")))
+        x = x + F.linear(h, g(p + "mlp.c_proj.weight"), g(p + "mlp.c_proj.bias"))
+    x = x.permute(1, 0, 2)
+    x = F.layer_norm(x, (d,), g("ln_final.weight"), g("ln_final.bias"), 1e-5)
+    xt = x[torch.arange(x.shape[0]), tokens.argmax(dim=-1)] @ g("text_projection")
+    return x, xt

@@ -163,7 +163,7 @@ def make_attn(dt, kind, seed=0, **p):
         ld = 3 * d
         return Attn(q=qkv, k=qkv[:, d:], v=qkv[:, 2 * d:], out=out, heads=heads, nq=N, nk=N, nbatch=nb,
                     inner=1, q_s=(ld, N * ld, 0), k_s=(ld, N * ld, 0), v_s=(ld, N * ld, 0),
-                    o_s=(d, N * d, 0), scale=0.125)
+                    o_s=(d, N * d, 0), scale=0.125, causal=p.get("causal", False))
     if kind == "cross":          # q [B*F*N, d]; kv [B*Lc, kw] slices
         B, F, N, Lc, off, kw = p["B"], p["F"], p["N"], p["Lc"], p["off"], p["kw"]
         q = torch.randn(B * F * N, d, generator=g).to(dt)
@@ -327,6 +327,10 @@ def tapgemm_cases(dt):
                                        colstats=True)
     c["cs_lin_wide_dual"] = make_tapgemm(dt, 9000, 1280, 128, colstats=True)
     c["temporal_b128"] = make_tapgemm(dt, 1 * 16 * 28, 128, 128, mode=L.TAP_TEMPORAL3, F=16, S=28)
+    # GELU epilogue (CLIP text MLP): 16-bit and fp32 out, ragged tiles, split-K reducer path
+    c["lin_gelu_154x4096x1024"] = make_tapgemm(dt, 154, 4096, 1024, epilogue=L.EPI_GELU, out_dtype=dt)
+    c["lin_gelu_f32_nonvec"] = make_tapgemm(dt, 90, 130, 128, epilogue=L.EPI_GELU)
+    c["lin_gelu_splitk"] = make_tapgemm(dt, 60, 256, 2048, epilogue=L.EPI_GELU, out_dtype=dt)
     return c
 
 
@@ -340,4 +344,9 @@ def attn_cases(dt):
     c["temporal_16"] = make_attn(dt, "temporal", heads=2, B=2, F=16, S=30)
     c["temporal_4"] = make_attn(dt, "temporal", heads=1, B=1, F=4, S=9, amp=2.0)
     c["temporal_32_flash"] = make_attn(dt, "temporal", heads=1, B=1, F=32, S=6)
+    # causal mask (CLIP text tower): 77 tokens (2 KV tiles, ragged), 200 (several Q tiles), 12 (<= 16: must not take
+    # the maskless temporal kernel)
+    c["causal_77"] = make_attn(dt, "spatial", heads=2, nb=3, N=77, causal=True)
+    c["causal_200"] = make_attn(dt, "spatial", heads=1, nb=2, N=200, causal=True, amp=2.0)
+    c["causal_12"] = make_attn(dt, "spatial", heads=1, nb=2, N=12, causal=True)
     return c

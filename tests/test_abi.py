@@ -45,6 +45,7 @@ def test_struct_layout_matches_header():
         names += [n.strip(" *") for n in decl.split(",")]
     assert names == [f[0] for f in lib.TapGemmArgs._fields_]
     body = re.search(r"typedef struct vgen_attn_args \{(.*?)\} vgen_attn_args;", src, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = []
     for decl in body.split(";"):
         decl = decl.strip()

@@ -156,3 +156,17 @@ def test_ddim_update_units_bit_exact(hip_backend):
     v = xud.view(G, B, Cs, F, H, W).cpu()
     assert torch.equal(v[0, :, :Cl], o.cpu()) and torch.equal(v[1, :, :Cl], o.cpu())
     assert torch.equal(v[:, :, Cl:], xu.view(G, B, Cs, F, H, W)[:, :, Cl:])          # stem channels untouched
+
+
+def test_embed_tokens_and_fp32_layernorm(hip_backend):
+    g = torch.Generator().manual_seed(2)
+    table, pos = torch.randn(300, 128, generator=g), torch.randn(20, 128, generator=g)
+    tok = torch.randint(0, 300, (3, 20), generator=g)
+    out = hip_backend.embed_tokens(tok.to(DEV), table.to(DEV), pos.to(DEV)).cpu()
+    assert torch.equal(out, kc.EMU.embed_tokens(tok, table, pos))
+    for d in (128, 1024, 1280):
+        x = torch.randn(77, d, generator=g) * 2 + 0.3
+        ga, be_ = torch.randn(d, generator=g), torch.randn(d, generator=g)
+        y = hip_backend.layernorm(x.to(DEV), ga.to(DEV), be_.to(DEV), 1e-5, torch.float32).cpu()
+        ref = torch.nn.functional.layer_norm(x.double(), (d,), ga.double(), be_.double(), 1e-5).float()
+        assert y.dtype == torch.float32 and float((y - ref).norm() / ref.norm()) < 2e-6

@@ -150,6 +150,9 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(const vgen_attn_args p, i
 
     // ---- online softmax; lane (lq, lr) holds keys kv0 + 16*kf + 4*lq + r of query lr ------
     const bool ragged = kv0 + BKV > p.nk;
+    // causal (CLIP text tower): key j is visible to query i iff j <= i.  Only tiles that reach past the wave's
+    // first query need the mask (wave-uniform test); key 0 is always visible, so every row keeps a finite maximum.
+    const bool diag = p.causal && kv0 + BKV - 1 > q0;
     u32x4 pb[2][2];
 #pragma unroll
     for (int f = 0; f < 2; ++f) {
@@ -159,6 +162,14 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(const vgen_attn_args p, i
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             s[f][kf][r] = (kv0 + kf * 16 + lq * 4 + r < p.nk) ? s[f][kf][r] : -INFINITY;
+      }
+      if (diag) {
+        const int qi = q0 + f * 16 + lr;
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            s[f][kf][r] = (kv0 + kf * 16 + lq * 4 + r <= qi) ? s[f][kf][r] : -INFINITY;
       }
       float mx = -INFINITY;
 #pragma unroll
@@ -340,7 +351,8 @@ extern "C" int vgen_attention(const vgen_attn_args* args, void* stream) {
                 a.o_rs | a.o_bo | a.o_bi) % 8 == 0,
                "attention: strides must be multiples of 8 elements");
   hipStream_t s = (hipStream_t)stream;
-  if (a.nq <= 16 && a.nk <= 16) {
+  VGEN_REQUIRE(a.causal == 0 || a.causal == 1, "attention: causal flag");
+  if (a.nq <= 16 && a.nk <= 16 && !a.causal) {
     const int64_t npairs = a.nbatch * a.heads;
     const int64_t grid = (npairs + 3) / 4;
     VGEN_REQUIRE(grid < (1LL << 31), "attention: grid too large");

@@ -167,6 +167,19 @@ __device__ __forceinline__ f32x4 geglu4(f32x4 val, f32x4 g) {
   return val * (h + h * e);
 }
 
+// gelu(x) on 4 values (exact-erf form, same polynomial as the GEGLU gate): the CLIP text tower's MLP activation
+__device__ __forceinline__ f32x4 gelu4(f32x4 g) {
+  const f32x4 one = {1.f, 1.f, 1.f, 1.f};
+  return geglu4(one, g);
+}
+
+// fp32 "storage type" for the kernels that can also emit unrounded values (dtype == VGEN_F32)
+struct F32Out {
+  static __device__ __forceinline__ float from_f32(float f) { return f; }
+};
+template <typename T> struct StoreOf { typedef uint16_t type; };
+template <> struct StoreOf<F32Out> { typedef float type; };
+
 // ---- host-side error plumbing (defined in cabi.cpp) -------------------------------------
 void vgen_set_error(const char* fmt, ...);
 int vgen_check_launch(const char* what);

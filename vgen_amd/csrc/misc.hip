@@ -15,13 +15,6 @@ __global__ __launch_bounds__(256) void act_cast_kernel(const float* __restrict__
   y[i] = T::from_f32(v);
 }
 
-struct F32Out {   // fp32 "storage type" for the kernels that can also emit unrounded values
-  typedef float store_t;
-  static __device__ __forceinline__ float from_f32(float f) { return f; }
-};
-template <typename T> struct StoreOf { typedef uint16_t type; };
-template <> struct StoreOf<F32Out> { typedef float type; };
-
 template <typename T>
 __global__ __launch_bounds__(256) void timestep_embedding_kernel(const float* __restrict__ t, int B,
                                                                  int dim,
@@ -91,6 +84,22 @@ __global__ __launch_bounds__(256) void linear_f32_kernel(const float* __restrict
       out[(int64_t)(r0 + r) * N + j] = v;
     }
   }
+}
+
+// CLIP text tower input: out[r, :] = table[tok[r], :] + pos[r % L, :]  (clip_embedder.py:155-156), fp32 rows
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const int64_t* __restrict__ tok, int64_t rows, int L, int d,
+                                                           int vocab, const float* __restrict__ table,
+                                                           const float* __restrict__ pos, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // one float4 per thread
+  const int d4 = d >> 2;
+  if (i >= rows * d4) return;
+  const int64_t r = i / d4;
+  const int c = (int)(i - r * d4) * 4;
+  int64_t t = tok[r];
+  t = t < 0 ? 0 : (t >= vocab ? vocab - 1 : t);
+  const f32x4 a = *(const f32x4*)(table + t * d + c);
+  const f32x4 b = *(const f32x4*)(pos + (r % L) * d + c);
+  *(f32x4*)(out + r * d + c) = a + b;
 }
 
 struct SrcGeom {
@@ -293,6 +302,19 @@ extern "C" int vgen_linear_f32(const float* x, int32_t n, int32_t K, const float
   hipLaunchKernelGGL(linear_f32_kernel, grid, dim3(256), lds, (hipStream_t)stream, x, n, K, W, bias, N, act_in,
                      add, out);
   return vgen_check_launch("linear_f32");
+}
+
+extern "C" int vgen_embed_tokens(const int64_t* tokens, int64_t rows, int32_t L, int32_t d, int32_t vocab,
+                                 const float* table, const float* pos, float* out, void* stream) {
+  VGEN_REQUIRE(rows > 0 && L > 0 && d > 0 && d % 4 == 0 && vocab > 0, "embed_tokens: sizes");
+  VGEN_REQUIRE(tokens && table && pos && out && vgen_aligned16(table) && vgen_aligned16(pos) && vgen_aligned16(out),
+               "embed_tokens: pointers");
+  const int64_t n = rows * (d / 4);
+  const int64_t grid = (n + 255) / 256;
+  VGEN_REQUIRE(grid < (1LL << 31), "embed_tokens: too large");
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, tokens, rows, L, d,
+                     vocab, table, pos, out);
+  return vgen_check_launch("embed_tokens");
 }
 
 extern "C" int vgen_im2col3x3_small(const float* src, int64_t nimg, int32_t Fi, int32_t Cin,

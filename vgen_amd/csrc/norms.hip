@@ -13,6 +13,7 @@
 // The input row is the virtual concat [x1 | x2] (decoder skip connections).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
@@ -471,7 +472,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
                                                         int d, float eps,
                                                         const float* __restrict__ gamma,
                                                         const float* __restrict__ beta,
-                                                        uint16_t* __restrict__ y) {
+                                                        void* __restrict__ y) {
   constexpr int RPB = 256 / LPR;  // rows per block
   const int sub = threadIdx.x % LPR;
   const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / LPR;
@@ -505,7 +506,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
   for (int o = LPR / 2; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
   const float rstd = 1.0f / sqrtf(q / (float)d + eps);
   if (!live) return;
-  uint16_t* yr = y + row * d;
 #pragma unroll
   for (int k = 0; k < LN_MAX_SLOTS; ++k) {
     const int slot = sub + LPR * k;
@@ -513,7 +513,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
       const f32x4 ga = *(const f32x4*)(gamma + slot * 4);
       const f32x4 be = *(const f32x4*)(beta + slot * 4);
       const f32x4 o = (v[k] - mean) * rstd * ga + be;
-      *(u32x2*)(yr + slot * 4) = pack4<T>(o.x, o.y, o.z, o.w);
+      if constexpr (std::is_same<T, F32Out>::value) {
+        *(f32x4*)((float*)y + row * d + slot * 4) = o;           // dtype VGEN_F32: unrounded (ln_final of the text tower)
+      } else {
+        *(u32x2*)((uint16_t*)y + row * d + slot * 4) = pack4<T>(o.x, o.y, o.z, o.w);
+      }
     }
   }
 }
@@ -589,7 +593,7 @@ void launch_ln_stream(const float* x, int64_t M, float eps, const float* gamma, 
 
 template <typename T, int LPR>
 void launch_ln(const float* x, int64_t M, int d, float eps, const float* gamma, const float* beta,
-               uint16_t* y, hipStream_t s) {
+               void* y, hipStream_t s) {
   const int64_t grid = (M + 256 / LPR - 1) / (256 / LPR);
   hipLaunchKernelGGL((layernorm_kernel<T, LPR>), dim3((unsigned)grid), dim3(256), 0, s, x, M, d, eps,
                      gamma, beta, y);
@@ -730,7 +734,7 @@ extern "C" int vgen_groupnorm_cs(const float* x1, int32_t C1, const float* cs1, 
 
 extern "C" int vgen_layernorm(const float* x, int64_t M, int32_t d, float eps, const float* gamma,
                               const float* beta, void* y, int32_t dtype, void* stream) {
-  VGEN_REQUIRE(dtype == VGEN_BF16 || dtype == VGEN_F16, "layernorm: dtype");
+  VGEN_REQUIRE(dtype == VGEN_BF16 || dtype == VGEN_F16 || dtype == VGEN_F32, "layernorm: dtype");
   VGEN_REQUIRE(d > 0 && d % 4 == 0 && d <= 64 * 4 * LN_MAX_SLOTS, "layernorm: d=%d", d);
   VGEN_REQUIRE(vgen_aligned16(x) && vgen_aligned16(y) && vgen_aligned16(gamma) &&
                    vgen_aligned16(beta),
@@ -738,6 +742,12 @@ extern "C" int vgen_layernorm(const float* x, int64_t M, int32_t d, float eps, c
   if (M <= 0) return 0;
   VGEN_REQUIRE(M < (1LL << 32), "layernorm: M too large");
   hipStream_t s = (hipStream_t)stream;
+  if (dtype == VGEN_F32) {
+    if (d <= 512) launch_ln<F32Out, 16>(x, M, d, eps, gamma, beta, y, s);
+    else if (d <= 1024) launch_ln<F32Out, 32>(x, M, d, eps, gamma, beta, y, s);
+    else launch_ln<F32Out, 64>(x, M, d, eps, gamma, beta, y, s);
+    return vgen_check_launch("layernorm");
+  }
   if (dtype == VGEN_BF16) dispatch_ln<BF16>(x, M, d, eps, gamma, beta, (uint16_t*)y, s);
   else dispatch_ln<F16>(x, M, d, eps, gamma, beta, (uint16_t*)y, s);
   return vgen_check_launch("layernorm");

@@ -14,8 +14,8 @@ LIB_PATH = os.path.join(HERE, "libvgen_hip.so")
 
 VGEN_BF16, VGEN_F16, VGEN_F32 = 0, 1, 2
 TAP_LINEAR, TAP_CONV3X3, TAP_TEMPORAL3 = 0, 1, 2
-EPI_NONE, EPI_GEGLU = 0, 1
-ABI_VERSION = 2
+EPI_NONE, EPI_GEGLU, EPI_GELU = 0, 1, 2
+ABI_VERSION = 3
 
 
 class VgenHipError(RuntimeError):
@@ -50,7 +50,7 @@ class AttnArgs(C.Structure):
         ("k_rs", C.c_int64), ("k_bo", C.c_int64), ("k_bi", C.c_int64),
         ("v_rs", C.c_int64), ("v_bo", C.c_int64), ("v_bi", C.c_int64),
         ("o_rs", C.c_int64), ("o_bo", C.c_int64), ("o_bi", C.c_int64),
-        ("scale", C.c_float),
+        ("scale", C.c_float), ("causal", C.c_int32),
     ]
 
 
@@ -73,6 +73,7 @@ SYMBOLS = {
     "vgen_softmax_rows": (C.c_int, [_vp, _i64, _i32, _i64, _f32, _vp, _i64, _i32, _vp]),
     "vgen_act_cast": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "vgen_timestep_embedding": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp]),
+    "vgen_embed_tokens": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "vgen_linear_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "vgen_im2col3x3_small": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64,
                                        _i64, _vp, _i32, _i32, _vp]),

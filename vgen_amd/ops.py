@@ -99,6 +99,7 @@ class Attn:
     v_s: tuple
     o_s: tuple
     scale: float
+    causal: bool = False
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -250,6 +251,7 @@ class HipBackend:
         a.v_rs, a.v_bo, a.v_bi = g.v_s
         a.o_rs, a.o_bo, a.o_bi = g.o_s
         a.scale = float(g.scale)
+        a.causal = int(bool(g.causal))
         with self._Prof("attention", 4.0 * g.nbatch * g.heads * g.nq * g.nk * 64,
                         (g.nbatch, g.heads, g.nq, g.nk)):
             rc = self.lib.vgen_attention(C.byref(a), self._stream(g.q))
@@ -275,6 +277,19 @@ class HipBackend:
             rc = self.lib.vgen_act_cast(_ptr(x), _ptr(y), x.numel(), int(act), _ENUM[dt], self._stream(x))
         _lib.check(rc, "vgen_act_cast")
         return y
+
+    def embed_tokens(self, tokens, table, pos):
+        """rows [B*L, d] fp32 = table[tokens] + pos (vgen_embed_tokens); tokens int64 [B, L]."""
+        assert tokens.dtype == torch.int64 and tokens.is_contiguous() and tokens.dim() == 2
+        assert table.dtype == torch.float32 and table.is_contiguous() and pos.dtype == torch.float32 and pos.is_contiguous()
+        B, Lk = tokens.shape
+        d = table.shape[1]
+        assert pos.shape == (Lk, d)
+        out = torch.empty((B * Lk, d), dtype=torch.float32, device=table.device)
+        rc = self.lib.vgen_embed_tokens(_ptr(tokens), B * Lk, Lk, d, table.shape[0], _ptr(table), _ptr(pos), _ptr(out),
+                                        self._stream(table))
+        _lib.check(rc, "vgen_embed_tokens")
+        return out
 
     def linear_f32(self, x, W, b, act_in=0, add=None):
         """out = act(x) @ W^T + b (+ add), fp32 (vgen_linear_f32)."""

@@ -91,6 +91,7 @@ def build_from_config(cfg, registry, **kwargs):
 
 MODEL = Registry("MODEL")
 AUTO_ENCODER = Registry("AUTO_ENCODER")
+EMBEDDER = Registry("EMBEDDER")
 DIFFUSION = Registry("DIFFUSION")
 
 
@@ -101,8 +102,9 @@ def _native_classes():
     from .unet_i2vgen import UNetSD_I2VGen
     from .unet_videolcm import UNetSD_TFT2V, UNetSD_VideoLCM
     from .vae import AutoencoderKL
+    from .clip_text import FrozenOpenCLIPEmbedder
     return {"MODEL": [UNetSD_T2VBase, UNetSD_SR600, UNetSD_I2VGen, UNetSD_VideoLCM, UNetSD_TFT2V], "AUTO_ENCODER": [AutoencoderKL],
-            "DIFFUSION": [DiffusionDDIM, DiffusionDDIMSR]}
+            "DIFFUSION": [DiffusionDDIM, DiffusionDDIMSR], "EMBEDDER": [FrozenOpenCLIPEmbedder]}
 
 
 def install(registries=None, quiet=True):
@@ -115,13 +117,16 @@ def install(registries=None, quiet=True):
     if registries is None:
         try:
             from utils import registry_class as rc      # reference tree on sys.path
-            registries = {"MODEL": rc.MODEL, "AUTO_ENCODER": rc.AUTO_ENCODER, "DIFFUSION": rc.DIFFUSION}
+            registries = {"MODEL": rc.MODEL, "AUTO_ENCODER": rc.AUTO_ENCODER, "DIFFUSION": rc.DIFFUSION,
+                          "EMBEDDER": rc.EMBEDDER}
         except Exception:
-            registries = {"MODEL": MODEL, "AUTO_ENCODER": AUTO_ENCODER, "DIFFUSION": DIFFUSION}
+            registries = {"MODEL": MODEL, "AUTO_ENCODER": AUTO_ENCODER, "DIFFUSION": DIFFUSION, "EMBEDDER": EMBEDDER}
     with warnings.catch_warnings():
         if quiet:
             warnings.simplefilter("ignore")
         for key, classes in _native_classes().items():
+            if key not in registries:             # caller passed a subset (e.g. only MODEL)
+                continue
             for cls in classes:
                 registries[key].register_class()(cls)
     return registries
