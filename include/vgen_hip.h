@@ -128,11 +128,10 @@ int vgen_layernorm(const float* x, int64_t M, int32_t d, float eps,
  *       [16 value rows | 16 gate rows] (packed index pn; value j <-> rows 32*(j/16)+j%16,
  *       gate j <-> +16), bias likewise; out[m, j] = v_value * gelu_erf(v_gate), j < N/2.
  *       (GEGLU.forward, util.py:712-714.)
- *   epilogue == VGEN_EPI_GELU: out = gelu_erf(v) (no residual; open_clip's mlp c_fc -> nn.GELU).
  *   out is fp32 or 16-bit (out_dtype), row stride ldo.
  */
 enum { VGEN_TAP_LINEAR = 0, VGEN_TAP_CONV3X3 = 1, VGEN_TAP_TEMPORAL3 = 2 };
-enum { VGEN_EPI_NONE = 0, VGEN_EPI_GEGLU = 1, VGEN_EPI_GELU = 2 };
+enum { VGEN_EPI_NONE = 0, VGEN_EPI_GEGLU = 1 };
 
 typedef struct vgen_tapgemm_args {
   int64_t M;
@@ -230,8 +229,9 @@ int vgen_softmax_rows(const float* S, int64_t rows, int32_t cols, int64_t lds, f
  * Small elementwise / layout kernels.
  */
 
-/* y = act(x) cast to 16-bit; act: 0 = identity, 1 = SiLU.  (nn.SiLU in time_embed /
- * emb_layers, unet_t2v.py:94, util.py:863.) */
+/* y = act(x) cast to 16-bit; act: 0 = identity, 1 = SiLU, 2 = exact (erf) GELU.  (nn.SiLU in time_embed /
+ * emb_layers, unet_t2v.py:94, util.py:863; nn.GELU of the OpenCLIP text tower's mlp.)  GELU is a separate pass on
+ * purpose: inside the tap-GEMM epilogue its polynomial cost the hot UNet instantiations 55-75 spilled VGPRs. */
 int vgen_act_cast(const float* x, void* y, int64_t n, int32_t act, int32_t dtype, void* stream);
 
 /* sinusoidal_embedding (util.py:178-190): out[b, :] = [cos(t_b * w_i) | sin(t_b * w_i)],

@@ -114,8 +114,6 @@ class EmuBackend:
             n_out = g.N
         if g.residual is not None:
             acc += g.residual[:, :n_out]
-        if g.epilogue == L.EPI_GELU:
-            acc = 0.5 * acc * (1.0 + torch.erf(acc * 0.7071067811865476))
         out = g.out
         if out is None:
             out = torch.empty((g.M, n_out), dtype=g.out_dtype)
@@ -158,6 +156,8 @@ class EmuBackend:
 
     # -- small kernels ---------------------------------------------------------------------------
     def act_cast(self, x, act, dt):
+        if act == 2:
+            return (0.5 * x * (1.0 + torch.erf(x * 0.7071067811865476))).to(dt)
         return (x * torch.sigmoid(x) if act == 1 else x).to(dt)
 
     def embed_tokens(self, tokens, table, pos):

@@ -235,6 +235,60 @@ def make_odd(R):
     print("vae_odd", tuple(dec.shape), tuple(mom.shape))
 
 
+def make_trajectory(R, full):
+    """a whole 50-step DDIM CFG trajectory of the reference (its own DiffusionDDIM driving its own
+    UNetSD_T2VBase, fp32 CPU) on the tiny fixture — final x0 and snapshots of x_t along the way, so the HIP path's
+    per-step drift can be reported — and, with --full, ONE full-size CFG step (2 forwards of the 1411 M model)."""
+    g = torch.load(os.path.join(GOLD, "unet_tiny.pt"), weights_only=False)
+    m = R["MODEL"].build(dict(type="UNetSD_T2VBase", **g["cfg"])).eval()
+    m.load_state_dict(torch_ref.synth_state_dict(g["shapes"], seed=g["seed"]), strict=True)
+    diff = R["DIFFUSION"].build(dict(type="DiffusionDDIM", **dict(DDIM_T2V, noise_strength=0.0)))
+    gen = torch.Generator("cpu").manual_seed(8888)
+    noise = torch.randn(g["x"].shape, generator=gen)
+    y_u = torch.randn(g["y"].shape, generator=gen)
+    kw = [dict(y=g["y"]), dict(y=y_u)]
+    steps = (1 + torch.arange(0, 1000, 20)).clamp(0, 999).flip(0)
+    snaps, xt = {}, noise.clone()
+    with torch.no_grad():
+        for i, step in enumerate(steps):
+            t = torch.full((noise.shape[0],), int(step), dtype=torch.long)
+            xt, _ = diff.ddim_sample(xt, t, m, kw, guide_scale=9.0, ddim_timesteps=50, eta=0.0)
+            if i in (0, 4, 9, 19, 29, 39, 49):
+                snaps[i] = xt.clone()
+    # the same trajectory under the reference's own production arithmetic (amp.autocast fp16 / bf16 around the model,
+    # fp32 sampler state: inference_text2video_entrance.py:197-206) — the drift yardstick
+    yard = {}
+    for dn, dt in (("fp16", torch.float16), ("bf16", torch.bfloat16)):
+        xa, dev_ = noise.clone(), {}
+        with torch.no_grad():
+            for i, step in enumerate(steps):
+                t = torch.full((noise.shape[0],), int(step), dtype=torch.long)
+                with torch.autocast("cpu", dtype=dt):
+                    xa, _ = diff.ddim_sample(xa, t, m, kw, guide_scale=9.0, ddim_timesteps=50, eta=0.0)
+                xa = xa.float()
+                if i in snaps:
+                    dev_[i] = float((xa - snaps[i]).norm() / snaps[i].norm())
+        yard[dn] = dev_
+        print("autocast", dn, dev_, flush=True)
+    torch.save(dict(noise=noise, y_u=y_u, snaps=snaps, guide_scale=9.0, ddim_timesteps=50, cfg=dict(DDIM_T2V, noise_strength=0.0),
+                    autocast_drift=yard),
+               os.path.join(GOLD, "ddim_traj_tiny.pt"))
+    print("ddim_traj_tiny", {k: float(v.std()) for k, v in snaps.items()})
+    if full:
+        g = torch.load(os.path.join(GOLD, "unet_t2v_full.pt"), weights_only=False)
+        m = R["MODEL"].build(dict(type="UNetSD_T2VBase", **g["cfg"])).eval()
+        m.load_state_dict(torch_ref.synth_state_dict(g["shapes"], seed=g["seed"]), strict=True)
+        gen = torch.Generator("cpu").manual_seed(g["input_seed"])
+        x = torch.randn(1, 4, 16, 32, 56, generator=gen)
+        y = torch.randn(1, 77, 1024, generator=gen)
+        y_u = torch.randn(1, 77, 1024, generator=gen)
+        t = torch.tensor([981])
+        with torch.no_grad():
+            xt1, x0 = diff.ddim_sample(x, t, m, [dict(y=y), dict(y=y_u)], guide_scale=9.0, ddim_timesteps=50, eta=0.0)
+        torch.save(dict(input_seed=g["input_seed"], t=t, xt1=xt1, x0=x0), os.path.join(GOLD, "ddim_step_full.pt"))
+        print("ddim_step_full", float(xt1.std()), float(x0.std()))
+
+
 def make_yardstick(R, full):
     """How far the reference's OWN mixed-precision arithmetic (amp.autocast, the mode its engines run:
     `use_fp16: True`, inference_text2video_entrance.py:197) lands from its fp32 forward on the fixtures' inputs —
@@ -295,6 +349,9 @@ def main():
         return
     if args.only == "odd":
         make_odd(R)
+        return
+    if args.only == "trajectory":
+        make_trajectory(R, args.full)
         return
     if args.only == "yardstick":
         make_yardstick(R, args.full)

@@ -327,10 +327,7 @@ def tapgemm_cases(dt):
                                        colstats=True)
     c["cs_lin_wide_dual"] = make_tapgemm(dt, 9000, 1280, 128, colstats=True)
     c["temporal_b128"] = make_tapgemm(dt, 1 * 16 * 28, 128, 128, mode=L.TAP_TEMPORAL3, F=16, S=28)
-    # GELU epilogue (CLIP text MLP): 16-bit and fp32 out, ragged tiles, split-K reducer path
-    c["lin_gelu_154x4096x1024"] = make_tapgemm(dt, 154, 4096, 1024, epilogue=L.EPI_GELU, out_dtype=dt)
-    c["lin_gelu_f32_nonvec"] = make_tapgemm(dt, 90, 130, 128, epilogue=L.EPI_GELU)
-    c["lin_gelu_splitk"] = make_tapgemm(dt, 60, 256, 2048, epilogue=L.EPI_GELU, out_dtype=dt)
+    c["lin_154x4096x1024_textmlp"] = make_tapgemm(dt, 154, 4096, 1024)
     return c
 
 

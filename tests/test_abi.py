@@ -78,3 +78,21 @@ def test_badarg_reported_without_gpu():
     a.M, a.N, a.dtype, a.C1, a.taps = 16, 16, lib.VGEN_BF16, 60, 1   # C1 not a multiple of 64
     rc = l.vgen_tapgemm(ctypes.byref(a), None)
     assert rc == -1 and b"C1" in l.vgen_last_error()
+
+
+def test_hot_kernels_have_no_register_spills(tmp_path):
+    """ISA guard (the dual 256x160 tap-GEMM sat at 256 VGPRs with 3 spilled; r02: a GELU branch in the
+    epilogue silently cost it 55-75 spilled VGPRs and 20 % of the bf16 step): every tap-GEMM / attention
+    instantiation must compile for gfx950 with .vgpr_spill_count == 0."""
+    import subprocess
+    from vgen_amd import build as b
+    for src in ("tapgemm.hip", "attention.hip"):
+        out = tmp_path / (src + ".s")
+        r = subprocess.run([b._hipcc()] + [f for f in b.FLAGS if f not in ("-fPIC",)] +
+                           ["-S", "--cuda-device-only", os.path.join(b.CSRC, src), "-o", str(out)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-2000:]
+        txt = out.read_text()
+        names = re.findall(r"\.name:\s+(\S+)", txt)
+        spills = [int(v) for v in re.findall(r"\.vgpr_spill_count:\s+(\d+)", txt)]
+        assert len(spills) >= 6 and all(s == 0 for s in spills), list(zip(names, spills))

@@ -74,6 +74,7 @@ def test_small_kernels(hip_backend, dtname):
     dt = kc.DTS[dtname]
     _check(kc.case_act_cast(hip_backend, DEV, dt, 5000, 1), dtname)
     _check(kc.case_act_cast(hip_backend, DEV, dt, 777, 0), dtname)
+    _check(kc.case_act_cast(hip_backend, DEV, dt, 4099, 2), dtname)          # exact GELU (text tower MLP)
     _check(kc.case_timestep_embedding(hip_backend, DEV, dt, 320), dtname)
     _check(kc.case_im2col(hip_backend, DEV, dt, "bcfhw"), dtname)
     _check(kc.case_im2col(hip_backend, DEV, dt, "rows"), dtname)

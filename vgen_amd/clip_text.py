@@ -18,7 +18,7 @@ it when open_clip is importable; the engines can equally pass token ids to `enco
 
 Execution: activations are rows [B*77, 1024]; fp32 residual stream, LayerNorm / tap-GEMM / causal flash attention
 kernels of libvgen_hip.so, 16-bit GEMM operands, fp32 accumulation — the same kernels as the UNet's transformer
-blocks (head_dim 64), plus the GELU epilogue and the token-embedding gather.
+blocks (head_dim 64), plus a GELU cast pass and the token-embedding gather.
 """
 from __future__ import annotations
 
@@ -159,8 +159,8 @@ class FrozenOpenCLIPEmbedder(nn.Module):
                               scale=HEAD_DIM ** -0.5, causal=True))
             x = be.tapgemm(TapGemm(A=o, W=blk["o"][0], M=M, N=d, C1=d, bias=blk["o"][1], residual=x))
             n = be.layernorm(x, *blk["ln2"], 1e-5, dt)
-            h = be.tapgemm(TapGemm(A=n, W=blk["fc"][0], M=M, N=blk["fc"][0].shape[0], C1=d, bias=blk["fc"][1],
-                                   out_dtype=dt, epilogue=L.EPI_GELU))
+            h = be.tapgemm(TapGemm(A=n, W=blk["fc"][0], M=M, N=blk["fc"][0].shape[0], C1=d, bias=blk["fc"][1]))
+            h = be.act_cast(h, 2, dt)                                         # nn.GELU, exact (erf) form
             x = be.tapgemm(TapGemm(A=h, W=blk["pr"][0], M=M, N=d, C1=h.shape[1], bias=blk["pr"][1], residual=x))
         return be.layernorm(x, *P["lnf"], 1e-5, torch.float32)
 

@@ -12,6 +12,7 @@ __global__ __launch_bounds__(256) void act_cast_kernel(const float* __restrict__
   if (i >= n) return;
   float v = x[i];
   if (act == 1) v = silu_f(v);
+  else if (act == 2) v = gelu_erf_f(v);
   y[i] = T::from_f32(v);
 }
 
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(256) void gaussian_sample_kernel(const float* __res
 extern "C" int vgen_act_cast(const float* x, void* y, int64_t n, int32_t act, int32_t dtype,
                              void* stream) {
   VGEN_REQUIRE(dtype == VGEN_BF16 || dtype == VGEN_F16, "act_cast: dtype");
+  VGEN_REQUIRE(act >= 0 && act <= 2, "act_cast: act");
   if (n <= 0) return 0;
   const int64_t grid = (n + 255) / 256;
   VGEN_REQUIRE(grid < (1LL << 31), "act_cast: n too large");

@@ -548,7 +548,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
           v += bv[ni];
           if (rbp) v += *(const f32x4*)(rbp + n);
           if (p.residual && !res_folded) v += *(const f32x4*)(p.residual + m * p.ldr + n);
-          if (p.epilogue == VGEN_EPI_GELU) v = gelu4(v);
           if (do_cs) {
             cs_s[ni] += v;
             cs_q[ni] += v * v;
@@ -566,7 +565,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
             if (p.bias) s += p.bias[n + r];
             if (rbp) s += rbp[n + r];
             if (p.residual) s += p.residual[m * p.ldr + n + r];
-            if (p.epilogue == VGEN_EPI_GELU) s = gelu_erf_f(s);
             if (p.out_dtype == VGEN_F32) of[m * p.ldo + n + r] = s;
             else oh[m * p.ldo + n + r] = T::from_f32(s);
           }
@@ -625,10 +623,6 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vgen_tapgemm_a
     v += *(const f32x4*)(p.rowbias + (m / p.rows_per_rb) * p.rowbias_ld + j);
   }
   if (p.residual) v += *(const f32x4*)(p.residual + m * p.ldr + j);
-  if (p.epilogue == VGEN_EPI_GELU) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = gelu_erf_f(v[r]);
-  }
   if (p.out_dtype == VGEN_F32) *(f32x4*)((float*)p.out + m * p.ldo + j) = v;
   else *(u32x2*)((uint16_t*)p.out + m * p.ldo + j) = pack4<T>(v.x, v.y, v.z, v.w);
 }
@@ -897,8 +891,6 @@ extern "C" int vgen_tapgemm(const vgen_tapgemm_args* args, void* stream) {
     VGEN_REQUIRE(a.N % 64 == 0 && a.rowbias == nullptr && (a.ldo % 4 == 0) &&
                      (a.residual == nullptr || a.ldr % 4 == 0),
                  "tapgemm: GEGLU needs N %% 64 == 0, no rowbias, ldo/ldr %% 4 == 0");
-  } else if (a.epilogue == VGEN_EPI_GELU) {
-    VGEN_REQUIRE(a.residual == nullptr && a.colstats == nullptr, "tapgemm: GELU epilogue takes no residual / colstats");
   } else {
     VGEN_REQUIRE(a.epilogue == VGEN_EPI_NONE, "tapgemm: unknown epilogue");
   }

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(HERE, "libvgen_hip.so")
 
 VGEN_BF16, VGEN_F16, VGEN_F32 = 0, 1, 2
 TAP_LINEAR, TAP_CONV3X3, TAP_TEMPORAL3 = 0, 1, 2
-EPI_NONE, EPI_GEGLU, EPI_GELU = 0, 1, 2
+EPI_NONE, EPI_GEGLU = 0, 1
 ABI_VERSION = 3
 
 
