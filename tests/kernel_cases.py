@@ -283,6 +283,12 @@ GN_CASES = [  # nb, S, C1, C2, silu, raw
     (2, 1792, 1280, 0, True, False), (3, 1001, 640, 640, True, True), (2, 12000, 320, 0, True, False),
     # single-launch kernel: slice just under the LDS bound, two-source rows, odd row counts
     (5, 409, 1280, 0, True, False), (3, 271, 640, 1280, False, True),
+    # register-resident single launch (24 K < slice <= 72 K elements): the 8x14-level 5-D norm, two sources with the raw
+    # copy, ragged last iteration, the upper bound of the path (36 iterations)
+    (2, 1792, 1280, 0, True, False), (2, 448, 1280, 1280, True, True), (1, 1003, 1920, 0, False, False),
+    (2, 1836, 1280, 0, True, False),
+    # just above it (37 iterations): back to the streaming pipeline
+    (2, 1837, 1280, 0, True, False),
 ]
 LN_CASES = [(100, 320), (7, 1280), (300, 64), (5, 512), (1, 2048), (40003, 320), (9001, 640), (3, 1024), (700, 1280), (50, 192)]
 

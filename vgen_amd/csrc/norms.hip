@@ -447,6 +447,92 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(
   }
 }
 
+// ---- single-launch GroupNorm, slice resident in REGISTERS ---------------------------------------------------
+// Slices too big for the LDS path above but <= 72 K elements (the 5-D norms of the 8x14 level: [1792 x 40] fp32 =
+// 287 KB per (batch, group)) used to take the three-launch streaming pipeline: 36 us for an 18 MB tensor, three
+// dependent launches that each re-read it.  A 1024-thread block can hold such a slice in its registers (72 floats
+// per thread): load once (the loads ARE the staging), block-reduce the mean, centred variance from the registers,
+// normalise + SiLU + store.  One launch, 6 B / element instead of 10.  Fixed reduction order.
+constexpr int GNR_THREADS = 1024;
+constexpr int GNR_NIT = 36;                       // float2 items per thread
+
+__device__ __forceinline__ float gnr_block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < GNR_THREADS / 64; ++i) t += red[i];
+  return t;
+}
+
+template <typename T>
+__global__ __launch_bounds__(GNR_THREADS) void gn_regs_kernel(
+    const float* __restrict__ x1, int C1, const float* __restrict__ x2, int C2, int64_t S, int groups,
+    float eps, const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
+    uint16_t* __restrict__ y, uint16_t* __restrict__ raw) {
+  __shared__ float red[GNR_THREADS / 64];
+  const int C = C1 + C2;
+  const int cpg = C / groups;
+  const int I = cpg >> 1;                       // float2 items per row of this group
+  const int rpi = GNR_THREADS / I;              // rows per block iteration
+  const int tid = threadIdx.x;
+  const int r0 = tid / I;
+  const int i = tid - r0 * I;
+  const bool active = r0 < rpi;
+  const int c = blockIdx.x * cpg + 2 * i;       // this thread's channel pair
+  const int64_t row0 = (int64_t)blockIdx.y * S;
+  const bool from1 = c < C1;
+  const float* src = from1 ? x1 + row0 * C1 + c : x2 + row0 * C2 + (c - C1);
+  const int64_t lds = from1 ? C1 : C2;
+  const int nit = active ? (int)((S - r0 + rpi - 1) / rpi) : 0;
+
+  f32x2 v[GNR_NIT];
+  float a = 0.f;
+  {
+    const float* p = src + (int64_t)r0 * lds;
+    const int64_t step = (int64_t)rpi * lds;
+#pragma unroll
+    for (int k = 0; k < GNR_NIT; ++k) {
+      v[k] = f32x2{0.f, 0.f};
+      if (k < nit) v[k] = *(const f32x2*)(p + k * step);
+    }
+#pragma unroll
+    for (int k = 0; k < GNR_NIT; ++k) a += v[k].x + v[k].y;      // rows beyond nit hold zeros
+  }
+  const float n = (float)S * (float)cpg;
+  const float mean = gnr_block_sum(a, red) / n;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < GNR_NIT; ++k) {
+    if (k < nit) {
+      const float d0 = v[k].x - mean, d1 = v[k].y - mean;
+      q += d0 * d0 + d1 * d1;
+    }
+  }
+  const float rstd = 1.0f / sqrtf(gnr_block_sum(q, red) / n + eps);
+  if (!active) return;
+  const float sc0 = gamma[c] * rstd, sc1 = gamma[c + 1] * rstd;
+  const float sh0 = beta[c] - mean * sc0, sh1 = beta[c + 1] - mean * sc1;
+  uint16_t* yo = y + (row0 + r0) * C + c;
+  uint16_t* ro = raw ? raw + (row0 + r0) * C + c : nullptr;
+  const int64_t ostep = (int64_t)rpi * C;
+#pragma unroll
+  for (int k = 0; k < GNR_NIT; ++k) {
+    if (k < nit) {
+      float o0 = v[k].x * sc0 + sh0, o1 = v[k].y * sc1 + sh1;
+      if (silu) {
+        o0 = silu_f(o0);
+        o1 = silu_f(o1);
+      }
+      *(uint32_t*)(yo + k * ostep) = T::pack2(o0, o1);
+      if (ro) *(uint32_t*)(ro + k * ostep) = T::pack2(v[k].x, v[k].y);
+    }
+  }
+}
+
 int gn_nsplit(int64_t nb, int64_t S, int C) {
   // ~16 K elements (64 KiB of fp32) per block, but at least ~1024 blocks overall when the tensor
   // allows it (>= 2 rows per block): the 4x7 / 8x14 levels are latency-bound, not bandwidth-bound.
@@ -676,6 +762,25 @@ static int groupnorm_impl(const float* x1, int32_t C1, const float* cs1, const f
                            gamma, beta, silu, (uint16_t*)y, (uint16_t*)raw);
       }
       return vgen_check_launch("gn_fused");
+    }
+  }
+  {
+    // register-resident single launch: slices that missed the LDS path but fit 72 floats x 1024 threads and are few
+    // enough that one block per slice is not the bottleneck (tuning switch: VGEN_GN_REGS=0 disables)
+    static const int regs_on = getenv("VGEN_GN_REGS") ? atoi(getenv("VGEN_GN_REGS")) : 1;
+    const int cpg = C / groups;
+    const int I = cpg / 2;
+    if (regs_on && cs1 == nullptr && cpg % 2 == 0 && C1 % 2 == 0 && I > 0 && I <= GNR_THREADS &&
+        (S + (GNR_THREADS / I) - 1) / (GNR_THREADS / I) <= GNR_NIT && nb * groups <= 1024 && S * cpg > GNF_LDS_FLOATS) {
+      dim3 fgrid((unsigned)groups, (unsigned)nb);
+      if (dtype == VGEN_BF16) {
+        hipLaunchKernelGGL(gn_regs_kernel<BF16>, fgrid, dim3(GNR_THREADS), 0, s, x1, C1, x2, C2, S, groups, eps, gamma, beta,
+                           silu, (uint16_t*)y, (uint16_t*)raw);
+      } else {
+        hipLaunchKernelGGL(gn_regs_kernel<F16>, fgrid, dim3(GNR_THREADS), 0, s, x1, C1, x2, C2, S, groups, eps, gamma, beta,
+                           silu, (uint16_t*)y, (uint16_t*)raw);
+      }
+      return vgen_check_launch("gn_regs");
     }
   }
   // rpb * C must fit the LDS staging of gn_stats (3072 floats per plane)

@@ -680,7 +680,9 @@ Plan make_plan(const vgen_tapgemm_args& a) {
   // runs one block in the same phase ("pp"); about half hidden with two independent blocks per CU
   const double epi_us = (double)a.M * n_out * ((a.out_dtype == VGEN_F32 ? 4 : 2) + (a.residual ? 4 : 0)) / 4.5e6;
   auto legal = [&](int shape, int bn, int sk) {
-    bool ok = false;
+    // BN = 64 is legal for any N as a forced / tabled plan (small-M levels: more, smaller tiles instead of split-K);
+    // the cost model itself only proposes it when neither 128 nor 160 divides N
+    bool ok = bn == 64 && a.N % 64 == 0 && (!geglu || a.N % 64 == 0);
     for (int c = 0; c < nc; ++c) ok |= cands[c] == bn;
     return ok && shape >= SHAPE_PP && shape <= SHAPE_PP128 && sk >= 1 && sk <= (smax < 1 ? 1 : smax) &&
            !(a.colstats && shape == SHAPE_PP128);
