@@ -97,7 +97,7 @@ __device__ __forceinline__ int swz_key(int row) {
 
 template <typename T, int BM, int BN, int BK, int WM, int WN, int STAGES, bool PP>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_kernel(
-    const vgen_tapgemm_args p, const int splitk, float* __restrict__ ws) {
+    const vgen_tapgemm_args p, const int splitk, float* __restrict__ ws, const int ablate) {
   static_assert(!PP || (WM * WN == 8 && STAGES == 3), "ping-pong needs 8 waves and a 3-stage ring");
   constexpr int NT = WM * WN * 64;              // threads
   constexpr int ROW_BYTES = BK * 2;             // bytes per LDS tile row
@@ -181,7 +181,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   const int split = blockIdx.y;
   const int kt_begin = (int)(((int64_t)KT * split) / splitk);
   const int kt_end = (int)(((int64_t)KT * (split + 1)) / splitk);
-  const int nk = kt_end - kt_begin;
+  // `ablate` (tuning switch VGEN_TAPGEMM_ABLATE, 0 in production): bit 0 skips the K loop, bit 1 the epilogue's
+  // stores — the phase decomposition of a launch (profiles/r02_tapgemm_ablation.json); bit 2 takes the 8-byte
+  // store path for 16-bit outputs (A/B of the paired 16-byte stores)
+  const int nk = (ablate & 1) ? 0 : kt_end - kt_begin;
 
   // ---- incremental per-lane DMA source pointers ---------------------------------------------
   // pc[j] = source of piece j for the NEXT K-tile to issue; consecutive K-tiles inside one tap /
@@ -473,6 +476,15 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   }
 
   // ---- epilogue -------------------------------------------------------------------------
+  if (ablate & 2) {   // keep the accumulators live (a store that never happens), skip everything else
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ni = 0; ni < NF; ++ni)
+#pragma unroll
+      for (int mi = 0; mi < MF; ++mi) t += acc[ni][mi];
+    if (t.x + t.y + t.z + t.w == 1.2345e30f) ((float*)p.out)[0] = t.x;
+    return;
+  }
   float* const of = (float*)p.out;
   uint16_t* const oh = (uint16_t*)p.out;
 
@@ -484,6 +496,83 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
       const int n = n0 + wn * WTN + ni * 16 + lq * 4;
       bv[ni] = (p.bias && n < p.N) ? *(const f32x4*)(p.bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
+  }
+  // ---- 16-bit outputs: their own epilogue loop (no column statistics live here: the dual shape has no registers
+  // to spare), two column fragments per store ----------------------------------------------------------------
+  if (vec && p.out_dtype != VGEN_F32 && (p.ldo & 7) == 0 && (!geglu || NF % 4 == 0) && !(ablate & 4)) {
+#pragma unroll
+    for (int mi = 0; mi < MF; ++mi) {
+      __builtin_amdgcn_sched_barrier(0);
+      const int64_t m = m0 + wm * WTM + mi * 16 + lr;
+      if (m >= p.M) continue;
+      const float* rbp = p.rowbias ? p.rowbias + (m / p.rows_per_rb) * p.rowbias_ld : nullptr;
+    // 16-bit outputs, two column fragments at a time.  A lane's C fragment is 4 consecutive n = 8 bytes: stored
+    // directly, a wave-level store covers 16 rows x 32 contiguous bytes per fragment and the write path runs at half
+    // its rate (ablation, profiles/r02_tapgemm_ablation.json: the epilogue of the 57344 x 960 x 320 qkv GEMM — 110 MB
+    // of stores — took 47 us = 2.3 TB/s and did not overlap the K loop; the fp32-output o-proj stores 16 B per lane
+    // at 4.7 TB/s).  v_permlane16_swap_b32 (gfx950) exchanges the odd 16-lane rows of one register with the even
+    // rows of another: after swapping the packed dwords of fragments (A, B) lane-row pairs, even rows hold 8
+    // consecutive n of fragment A and odd rows 8 consecutive n of fragment B — one 16-byte store per lane, 64
+    // contiguous bytes per output row per instruction.  (r01 staged such stores through LDS: the extra barrier + LDS
+    // round trip cost more than it won; this exchange is two register-only instructions per fragment pair.)
+    auto store_pair16 = [&](int frag0_col, bool pair_ok, const f32x4& va, const f32x4& vb, int64_t m_) __attribute__((always_inline)) {
+      // frag0_col: column of fragment A's n = 0; fragment B starts 16 columns later
+      u32x2 pa = pack4<T>(va.x, va.y, va.z, va.w);
+      u32x2 pb = pack4<T>(vb.x, vb.y, vb.z, vb.w);
+      if (pair_ok) {
+        const auto sx = __builtin_amdgcn_permlane16_swap(pa.x, pb.x, false, false);
+        const auto sy = __builtin_amdgcn_permlane16_swap(pa.y, pb.y, false, false);
+        const u32x4 q = {sx[0], sy[0], sx[1], sy[1]};
+        *(u32x4*)(oh + m_ * p.ldo + frag0_col + (lq & 1) * 16 + (lq >> 1) * 8) = q;
+      } else {
+        if (frag0_col + lq * 4 < n_out) *(u32x2*)(oh + m_ * p.ldo + frag0_col + lq * 4) = pa;
+        if (frag0_col + 16 + lq * 4 < n_out) *(u32x2*)(oh + m_ * p.ldo + frag0_col + 16 + lq * 4) = pb;
+      }
+    };
+      if (!geglu) {
+        auto final_val = [&](int ni) __attribute__((always_inline)) -> f32x4 {      // bias / row-bias / residual
+          const int n = n0 + wn * WTN + ni * 16 + lq * 4;
+          f32x4 v = acc[ni][mi];
+          if (n < p.N) {
+            v += bv[ni];
+            if (rbp) v += *(const f32x4*)(rbp + n);
+            if (p.residual && !res_folded) v += *(const f32x4*)(p.residual + m * p.ldr + n);
+          }
+          return v;
+        };
+#pragma unroll
+        for (int ni = 0; ni + 1 < NF; ni += 2) {
+          const int c0 = n0 + wn * WTN + ni * 16;
+          store_pair16(c0, c0 + 32 <= p.N, final_val(ni), final_val(ni + 1), m);
+        }
+        if constexpr (NF % 2 == 1) {
+          const int n = n0 + wn * WTN + (NF - 1) * 16 + lq * 4;
+          if (n < p.N) {
+            const f32x4 v = final_val(NF - 1);
+            *(u32x2*)(oh + m * p.ldo + n) = pack4<T>(v.x, v.y, v.z, v.w);
+          }
+        }
+      } else if constexpr (NF % 4 == 0) {
+        auto gated = [&](int np) __attribute__((always_inline)) -> f32x4 {
+          const int pn = n0 + wn * WTN + np * 32 + lq * 4;  // packed index of the value lanes
+          const int j = (n0 + wn * WTN) / 2 + np * 16 + lq * 4;
+          f32x4 o = {0.f, 0.f, 0.f, 0.f};
+          if (pn < p.N) {
+            const f32x4 val = acc[2 * np][mi] + bv[2 * np];
+            const f32x4 gat = acc[2 * np + 1][mi] + bv[2 * np + 1];
+            o = geglu4(val, gat);
+            if (p.residual) o += *(const f32x4*)(p.residual + m * p.ldr + j);
+          }
+          return o;
+        };
+#pragma unroll
+        for (int np = 0; np < NF / 2; np += 2) {
+          const int j0 = (n0 + wn * WTN) / 2 + np * 16;
+          store_pair16(j0, j0 + 32 <= n_out, gated(np), gated(np + 1), m);
+        }
+      }
+    }
+    return;
   }
   // column statistics of the final fp32 values per 64-row slab (vgen_tapgemm_args.colstats): the wave
   // tile is 64 ("pp") or 128 ("dual") rows = 1 or 2 whole slabs, so no cross-wave step is needed.
@@ -572,15 +661,24 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
       }
     } else if constexpr (NF % 2 == 0) {
       // packed columns: fragment pairs (value, gate) = (ni even, ni odd)
+      auto gated = [&](int np) __attribute__((always_inline)) -> f32x4 {
+        const int pn = n0 + wn * WTN + np * 32 + lq * 4;  // packed index of the value lanes
+        const int j = (n0 + wn * WTN) / 2 + np * 16 + lq * 4;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        if (pn < p.N) {
+          const f32x4 val = acc[2 * np][mi] + bv[2 * np];
+          const f32x4 gat = acc[2 * np + 1][mi] + bv[2 * np + 1];
+          o = geglu4(val, gat);
+          if (p.residual) o += *(const f32x4*)(p.residual + m * p.ldr + j);
+        }
+        return o;
+      };
 #pragma unroll
       for (int np = 0; np < NF / 2; ++np) {
-        const int pn = n0 + wn * WTN + np * 32 + lq * 4;  // packed index of the value lanes
+        const int pn = n0 + wn * WTN + np * 32 + lq * 4;
         if (pn >= p.N) continue;
         const int j = (n0 + wn * WTN) / 2 + np * 16 + lq * 4;
-        const f32x4 val = acc[2 * np][mi] + bv[2 * np];
-        const f32x4 gat = acc[2 * np + 1][mi] + bv[2 * np + 1];
-        f32x4 o = geglu4(val, gat);
-        if (p.residual) o += *(const f32x4*)(p.residual + m * p.ldr + j);
+        const f32x4 o = gated(np);
         if (p.out_dtype == VGEN_F32) {
           *(f32x4*)(of + m * p.ldo + j) = o;
         } else {
@@ -770,8 +868,9 @@ int launch(const vgen_tapgemm_args& a, int splitk, hipStream_t stream) {
   }
   if (splitk > 1 && (a.ws == nullptr || a.ws_bytes < (size_t)splitk * a.M * a.N * sizeof(float)))
     splitk = 1;   // caller did not provide the workspace: still correct, just fewer blocks
+  const char* ab = getenv("VGEN_TAPGEMM_ABLATE");
   hipLaunchKernelGGL((tapgemm_kernel<T, BM, BN, BK, WM, WN, STAGES, PP>), dim3((unsigned)grid, (unsigned)splitk),
-                     dim3(WM * WN * 64), lds, stream, a, splitk, (float*)a.ws);
+                     dim3(WM * WN * 64), lds, stream, a, splitk, (float*)a.ws, ab ? atoi(ab) : 0);
   int rc = vgen_check_launch("tapgemm");
   if (rc || splitk == 1) return rc;
   const int n_out = a.epilogue == VGEN_EPI_GEGLU ? a.N / 2 : a.N;
