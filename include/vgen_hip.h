@@ -326,6 +326,32 @@ int vgen_lowfreq_filter(const float* x, int64_t nimg, int32_t H, int32_t W, int3
 /* x[:, c0:c1] *= s in place on rows [M, C] fp32 (unet_sr600.py:278,284: backbone half-channel boost). */
 int vgen_scale_channels(float* x, int64_t M, int32_t C, int32_t c0, int32_t c1, float s, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Condition stems ahead of the trunk (prompt constants: evaluated once per sampling session).  fp32, NCHW frames.
+ *
+ * vgen_conv3x3_small: y = act(conv2d(x, w, b, stride, padding = 1)), x [n, Cin, H, W], w [Cout, Cin, 3, 3],
+ *   act 0 = none, 1 = SiLU — the nn.Conv2d(+nn.SiLU) of local_image_concat / local_image_embedding
+ *   (unet_i2vgen.py:116-132) and of the depth / motion / canny / mask / sketch / local_image stems
+ *   (unet_videolcm.py:294-372).
+ * vgen_adaptive_avgpool2d: nn.AdaptiveAvgPool2d((Ho, Wo)) over `planes` = n*C planes of H x W (same stems).
+ * vgen_frame_transformer: ONE layer of TransformerV2 over the frame axis of every pixel (util.py:1396-1453,
+ *   used at unet_i2vgen.py:289-293 and unet_videolcm.py:606-699): x tokens [B, F, d, HW] (frames of d channels),
+ *   x <- to_out(MHA(LayerNorm(x))) + x ; x <- W2 gelu(W1 x + b1) + b2 + x.  wqkv [3*heads*dim_head, d] (no bias),
+ *   wout [d, heads*dim_head] / bout [d] (both NULL when heads == 1 && dim_head == d: identity), w1 [hidden, d],
+ *   w2 [d, hidden].  last == 0: y in the input layout; last == 1: y is the trunk's stem-channel layout
+ *   [B, d, F, HW], value * out_scale, added to y when `accumulate` (the composer sums its stems,
+ *   unet_videolcm.py:612-699; UNetSD_I2VGen adds its map twice, unet_i2vgen.py:294-295).
+ *   F <= 32, d <= 16, heads*dim_head <= 32, hidden <= 64. */
+int vgen_conv3x3_small(const float* x, int64_t n, int32_t Cin, int32_t H, int32_t W, const float* w,
+                       const float* b, int32_t Cout, int32_t stride, int32_t act, float* y, void* stream);
+int vgen_adaptive_avgpool2d(const float* x, int64_t planes, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                            float* y, void* stream);
+int vgen_frame_transformer(const float* x, int64_t B, int32_t F, int32_t d, int64_t HW, int32_t heads,
+                           int32_t dim_head, int32_t hidden, const float* ln_w, const float* ln_b,
+                           const float* wqkv, const float* wout, const float* bout, const float* w1,
+                           const float* b1, const float* w2, const float* b2, float* y, int32_t last,
+                           float out_scale, int32_t accumulate, void* stream);
+
 /* Decoded frames to displayable bytes — the step right after AutoencoderKL.decode in every engine:
  * utils/video_op.py:181-188 (`gen_video.mul_(std).add_(mean)`, `clamp_(0, 1)`, `* 255.0`, rearrange
  * 'b c f h w -> b f h w c', `.astype('uint8')`).  x: decoder output rows [rows = n*H*W, C] fp32 (row stride

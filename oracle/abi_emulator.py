@@ -160,6 +160,40 @@ class EmuBackend:
             return (0.5 * x * (1.0 + torch.erf(x * 0.7071067811865476))).to(dt)
         return (x * torch.sigmoid(x) if act == 1 else x).to(dt)
 
+    def conv3x3_small(self, x, w, b, stride=1, act=0):
+        y = torch.nn.functional.conv2d(x, w, b, stride=stride, padding=1)
+        return y * torch.sigmoid(y) if act == 1 else y
+
+    def adaptive_avgpool2d(self, x, Ho, Wo):
+        return torch.nn.functional.adaptive_avg_pool2d(x, (Ho, Wo))
+
+    def frame_transformer(self, x, B, F, d, HW, p, out=None, last=False, out_scale=1.0, accumulate=False):
+        Fn = torch.nn.functional
+        t = x.reshape(B, F, d, HW).permute(0, 3, 1, 2)                      # [B, HW, F, d]
+        n = Fn.layer_norm(t, (d,), p["ln_w"], p["ln_b"], 1e-5)
+        h, dh = p["heads"], p["dim_head"]
+        qkv = (n @ p["wqkv"].t()).view(B, HW, F, 3, h, dh).permute(3, 0, 1, 4, 2, 5)
+        w = torch.softmax(qkv[0] @ qkv[1].transpose(-1, -2) * dh ** -0.5, dim=-1)
+        o = (w @ qkv[2]).permute(0, 1, 3, 2, 4).reshape(B, HW, F, h * dh)
+        if p["wout"] is not None:
+            o = o @ p["wout"].t() + p["bout"]
+        t = t + o
+        t = Fn.linear(Fn.gelu(Fn.linear(t, p["w1"], p["b1"])), p["w2"], p["b2"]) + t
+        if not last:
+            r = t.permute(0, 2, 3, 1).reshape(x.shape)                         # back to frames [B*F, d, H, W]
+            if out is None:
+                return r.contiguous()
+            out.view_as(r).copy_(r)
+            return out
+        r = (t.permute(0, 3, 2, 1) * out_scale).reshape(-1)                    # [B, d, F, HW]
+        if out is None:
+            return r.contiguous()
+        if accumulate:
+            out.view(-1).add_(r)
+        else:
+            out.view(-1).copy_(r)
+        return out
+
     def embed_tokens(self, tokens, table, pos):
         B, Lk = tokens.shape
         return (table[tokens.clamp(0, table.shape[0] - 1)] + pos[None]).reshape(B * Lk, -1).contiguous()

@@ -171,3 +171,39 @@ def test_embed_tokens_and_fp32_layernorm(hip_backend):
         y = hip_backend.layernorm(x.to(DEV), ga.to(DEV), be_.to(DEV), 1e-5, torch.float32).cpu()
         ref = torch.nn.functional.layer_norm(x.double(), (d,), ga.double(), be_.double(), 1e-5).float()
         assert y.dtype == torch.float32 and float((y - ref).norm() / ref.norm()) < 2e-6
+
+
+def test_condition_stem_kernels(hip_backend):
+    """vgen_conv3x3_small / vgen_adaptive_avgpool2d / vgen_frame_transformer (fp32) vs torch on the same inputs."""
+    g = torch.Generator().manual_seed(4)
+    for n, cin, cout, H, W, stride, act in ((3, 4, 16, 11, 9, 1, 1), (2, 16, 4, 8, 8, 1, 0), (2, 32, 64, 32, 32, 2, 1),
+                                            (1, 64, 1024, 16, 16, 2, 0), (2, 1, 32, 24, 40, 1, 1)):
+        x = torch.randn(n, cin, H, W, generator=g)
+        w = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+        b = torch.randn(cout, generator=g)
+        y = hip_backend.conv3x3_small(x.to(DEV), w.to(DEV), b.to(DEV), stride=stride, act=act).cpu()
+        ref = kc.EMU.conv3x3_small(x, w, b, stride=stride, act=act)
+        assert y.shape == ref.shape and float((y - ref).norm() / ref.norm()) < 2e-6, (n, cin, cout, H, W, stride)
+    for H, W, Ho, Wo in ((88, 160, 32, 32), (24, 40, 12, 20), (7, 5, 3, 4), (16, 16, 16, 16)):
+        x = torch.randn(2, 5, H, W, generator=g)
+        y = hip_backend.adaptive_avgpool2d(x.to(DEV), Ho, Wo).cpu()
+        assert float((y - kc.EMU.adaptive_avgpool2d(x, Ho, Wo)).abs().max()) < 1e-6
+    for B, F, d, H, W, heads, dh, hidden, has_out in ((2, 16, 4, 5, 7, 2, 4, 16, True), (1, 32, 8, 3, 4, 2, 8, 32, True),
+                                                      (2, 3, 8, 2, 2, 1, 8, 32, False)):
+        inner = heads * dh
+        p = dict(ln_w=1 + 0.2 * torch.randn(d, generator=g), ln_b=0.2 * torch.randn(d, generator=g),
+                 wqkv=torch.randn(3 * inner, d, generator=g) / d ** 0.5,
+                 wout=torch.randn(d, inner, generator=g) / inner ** 0.5 if has_out else None,
+                 bout=0.1 * torch.randn(d, generator=g) if has_out else None,
+                 w1=torch.randn(hidden, d, generator=g) / d ** 0.5, b1=0.1 * torch.randn(hidden, generator=g),
+                 w2=torch.randn(d, hidden, generator=g) / hidden ** 0.5, b2=0.1 * torch.randn(d, generator=g),
+                 heads=heads, dim_head=dh, hidden=hidden)
+        pd = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in p.items()}
+        x = torch.randn(B * F, d, H, W, generator=g)
+        mid = hip_backend.frame_transformer(x.to(DEV), B, F, d, H * W, pd).cpu()
+        assert float((mid - kc.EMU.frame_transformer(x, B, F, d, H * W, p)).norm() / mid.norm()) < 5e-6
+        base = torch.randn(B * d * F * H * W, generator=g)
+        out = hip_backend.frame_transformer(x.to(DEV), B, F, d, H * W, pd, out=base.clone().to(DEV), last=True,
+                                            out_scale=2.0, accumulate=True).cpu()
+        ref = kc.EMU.frame_transformer(x, B, F, d, H * W, p, out=base.clone(), last=True, out_scale=2.0, accumulate=True)
+        assert float((out - ref).norm() / ref.norm()) < 5e-6

@@ -167,6 +167,9 @@ __device__ __forceinline__ f32x4 geglu4(f32x4 val, f32x4 g) {
   return val * (h + h * e);
 }
 
+// exact GELU on libm's erff (condition stems: once per prompt, not performance relevant)
+__device__ __forceinline__ float gelu_erf_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
 // gelu(x) on 4 values (exact-erf form, same polynomial as the GEGLU gate): the CLIP text tower's MLP activation
 __device__ __forceinline__ f32x4 gelu4(f32x4 g) {
   const f32x4 one = {1.f, 1.f, 1.f, 1.f};

@@ -73,6 +73,10 @@ SYMBOLS = {
     "vgen_softmax_rows": (C.c_int, [_vp, _i64, _i32, _i64, _f32, _vp, _i64, _i32, _vp]),
     "vgen_act_cast": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "vgen_timestep_embedding": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp]),
+    "vgen_conv3x3_small": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "vgen_adaptive_avgpool2d": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "vgen_frame_transformer": (C.c_int, [_vp, _i64, _i32, _i32, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                         _vp, _vp, _vp, _vp, _i32, _f32, _i32, _vp]),
     "vgen_embed_tokens": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "vgen_linear_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "vgen_im2col3x3_small": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64,

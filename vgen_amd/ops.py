@@ -278,6 +278,44 @@ class HipBackend:
         _lib.check(rc, "vgen_act_cast")
         return y
 
+    # -- condition stems (fp32, NCHW frames; once per sampling session) ------------------------------------
+    def conv3x3_small(self, x, w, b, stride=1, act=0):
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+        assert w.dtype == torch.float32 and w.is_contiguous() and w.shape[1] == x.shape[1] and tuple(w.shape[2:]) == (3, 3)
+        n, cin, H, W = x.shape
+        cout = w.shape[0]
+        Ho, Wo = (H + 2 - 3) // stride + 1, (W + 2 - 3) // stride + 1
+        y = torch.empty((n, cout, Ho, Wo), dtype=torch.float32, device=x.device)
+        rc = self.lib.vgen_conv3x3_small(_ptr(x), n, cin, H, W, _ptr(w), _ptr(b), cout, int(stride), int(act), _ptr(y),
+                                         self._stream(x))
+        _lib.check(rc, "vgen_conv3x3_small")
+        return y
+
+    def adaptive_avgpool2d(self, x, Ho, Wo):
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 4
+        n, c, H, W = x.shape
+        y = torch.empty((n, c, Ho, Wo), dtype=torch.float32, device=x.device)
+        rc = self.lib.vgen_adaptive_avgpool2d(_ptr(x), n * c, H, W, int(Ho), int(Wo), _ptr(y), self._stream(x))
+        _lib.check(rc, "vgen_adaptive_avgpool2d")
+        return y
+
+    def frame_transformer(self, x, B, F, d, HW, p, out=None, last=False, out_scale=1.0, accumulate=False):
+        """One TransformerV2 layer over frames (vgen_frame_transformer).  x: frames [B*F, d, H, W] fp32; p: dict of
+        fp32 tensors ln_w, ln_b, wqkv, wout, bout, w1, b1, w2, b2 + ints heads, dim_head, hidden.  `last`: result in
+        [B, d, F, H, W] layout into `out` (scaled / accumulated)."""
+        assert x.dtype == torch.float32 and x.is_contiguous() and x.numel() == B * F * d * HW
+        if out is None:
+            out = torch.empty_like(x) if not last else torch.empty((B * d * F * HW,), dtype=torch.float32, device=x.device)
+        assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == x.numel()
+        for k in ("ln_w", "ln_b", "wqkv", "wout", "bout", "w1", "b1", "w2", "b2"):
+            assert p[k] is None or (p[k].dtype == torch.float32 and p[k].is_contiguous()), k
+        rc = self.lib.vgen_frame_transformer(_ptr(x), B, F, d, HW, p["heads"], p["dim_head"], p["hidden"], _ptr(p["ln_w"]),
+                                             _ptr(p["ln_b"]), _ptr(p["wqkv"]), _ptr(p["wout"]), _ptr(p["bout"]),
+                                             _ptr(p["w1"]), _ptr(p["b1"]), _ptr(p["w2"]), _ptr(p["b2"]), _ptr(out),
+                                             int(bool(last)), float(out_scale), int(bool(accumulate)), self._stream(x))
+        _lib.check(rc, "vgen_frame_transformer")
+        return out
+
     def embed_tokens(self, tokens, table, pos):
         """rows [B*L, d] fp32 = table[tokens] + pos (vgen_embed_tokens); tokens int64 [B, L]."""
         assert tokens.dtype == torch.int64 and tokens.is_contiguous() and tokens.dim() == 2

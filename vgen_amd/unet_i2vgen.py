@@ -8,8 +8,9 @@ context (77 text tokens + 64 local-image tokens + `num_tokens` global-image toke
 The condition stems that produce those extras depend only on the conditioning image, not on x or t:
 the reference recomputes them on every denoise step (unet_i2vgen.py:280-321), here they are evaluated
 once per conditioning input and cached.  They are tiny (4..64-channel convs, an 8x8-token pooling
-pyramid, a 4-wide one-layer transformer over frames) and run through plain torch modules on the
-device — prompt-constant plumbing ahead of the hot path (SURVEY §8 f2 lists native stems as "next").
+pyramid, a 4-wide one-layer transformer over frames) and run on the C ABI's stem kernels
+(vgen_conv3x3_small / vgen_adaptive_avgpool2d / vgen_frame_transformer / vgen_linear_f32, fp32; SURVEY §8 f2);
+the nn.Modules below only hold the parameters.
 Parameter names / shapes equal the reference's, so stock checkpoints load strict.
 """
 from __future__ import annotations
@@ -18,7 +19,65 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F_
 
+from . import ops
 from .unet import UNetSD_T2VBase
+
+
+# ------------------------------------------------------------------------------------------
+# native condition stems: the nn.Modules below are parameter containers; these helpers run them
+# on the C ABI (vgen_conv3x3_small / vgen_adaptive_avgpool2d / vgen_frame_transformer / vgen_linear_f32)
+# ------------------------------------------------------------------------------------------
+def _p32(t):
+    return t.detach().float().contiguous()
+
+
+def conv_stack(x, seq):
+    """nn.Sequential of Conv2d(3x3, padding 1, stride 1|2) / SiLU / AdaptiveAvgPool2d on NCHW fp32 frames."""
+    be = ops.backend()
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Conv2d):
+            assert m.kernel_size == (3, 3) and m.padding == (1, 1) and m.stride[0] == m.stride[1]
+            act = 1 if i + 1 < len(mods) and isinstance(mods[i + 1], nn.SiLU) else 0
+            x = be.conv3x3_small(x, _p32(m.weight), _p32(m.bias), stride=m.stride[0], act=act)
+            i += 2 if act else 1
+        elif isinstance(m, nn.AdaptiveAvgPool2d):
+            ho, wo = m.output_size
+            x = be.adaptive_avgpool2d(x, ho, wo)
+            i += 1
+        else:
+            raise TypeError(type(m))
+    return x
+
+
+def frame_transformer(tf, frames, B, F, out=None, out_scale=1.0, accumulate=False):
+    """`tf` (_FrameTransformer) over the frame axis of every pixel: frames [(B F), d, H, W] -> [B, d, F, H, W]."""
+    be = ops.backend()
+    d, H, W = frames.shape[1:]
+    n = len(tf.layers)
+    x = frames
+    for li, (attn_pre, mlp) in enumerate(tf.layers):
+        attn = attn_pre.fn
+        inner = attn.to_qkv.weight.shape[0] // 3
+        has_out = not isinstance(attn.to_out, nn.Identity)
+        p = dict(ln_w=_p32(attn_pre.norm.weight), ln_b=_p32(attn_pre.norm.bias), wqkv=_p32(attn.to_qkv.weight),
+                 wout=_p32(attn.to_out[0].weight) if has_out else None, bout=_p32(attn.to_out[0].bias) if has_out else None,
+                 w1=_p32(mlp.net[0][0].weight), b1=_p32(mlp.net[0][0].bias), w2=_p32(mlp.net[2].weight), b2=_p32(mlp.net[2].bias),
+                 heads=attn.heads, dim_head=inner // attn.heads, hidden=mlp.net[0][0].weight.shape[0])
+        last = li == n - 1
+        x = be.frame_transformer(x, B, F, d, H * W, p, out=out if last else None, last=last,
+                                 out_scale=out_scale if last else 1.0, accumulate=accumulate and last)
+    return x.view(B, d, F, H, W)
+
+
+def mlp_f32(x, seq):
+    """Linear - SiLU - Linear (context / histogram embeddings) on vgen_linear_f32; x [n, K] fp32."""
+    be = ops.backend()
+    l0, l2 = seq[0], seq[2]
+    h = be.linear_f32(x.float().contiguous(), _p32(l0.weight), _p32(l0.bias))
+    return be.linear_f32(h, _p32(l2.weight), _p32(l2.bias), act_in=1)
 
 
 class _FrameAttention(nn.Module):
@@ -140,17 +199,15 @@ class UNetSD_I2VGen(UNetSD_T2VBase):
         frames = [li]
         for tpos in range(F - 1):
             frames.append(torch.full_like(li, (tpos + 1) / (F - 1)))
-        xi = torch.cat(frames, 2).permute(0, 2, 1, 3, 4).reshape(B * F, li.shape[1], H, W)
-        xi = self.local_image_concat(xi)                                           # [(B F), cc, H, W]
-        cc = xi.shape[1]
-        seq = xi.view(B, F, cc, H, W).permute(0, 3, 4, 1, 2).reshape(B * H * W, F, cc)
-        seq = self.local_temporal_encoder(seq)
-        concat = seq.view(B, H, W, F, cc).permute(0, 4, 3, 1, 2)
-        concat = (concat + concat).contiguous()          # the reference adds the map twice (:294-295), kept
-        lc = self.local_image_embedding(li[:, :, 0])                               # [B, 1024, 8, 8]
+        xi = torch.cat(frames, 2).permute(0, 2, 1, 3, 4).reshape(B * F, li.shape[1], H, W).contiguous()
+        xi = conv_stack(xi, self.local_image_concat)                               # [(B F), cc, H, W]
+        # TransformerV2 over the frames of every pixel, written straight into the stem-channel layout; the reference
+        # adds the map twice (:294-295), kept: scale 2
+        concat = frame_transformer(self.local_temporal_encoder, xi, B, F, out_scale=2.0)
+        lc = conv_stack(li[:, :, 0].contiguous(), self.local_image_embedding)      # [B, 1024, 8, 8]
         extra = lc.flatten(2).transpose(1, 2)                                      # [B, 64, 1024]
         if image is not None:
-            ic = self.context_embedding(image.float()).view(-1, self.num_tokens, self.context_dim)
+            ic = mlp_f32(image.reshape(-1, image.shape[-1]), self.context_embedding).view(-1, self.num_tokens, self.context_dim)
             extra = torch.cat([extra, ic], 1)
         out = (concat, extra.contiguous())
         if len(cache) >= 8:                              # a handful of prompts in flight; never grows unbounded

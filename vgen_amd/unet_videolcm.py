@@ -8,7 +8,7 @@ text tokens (:714-741) plus, with 'image', num_tokens tokens from `pre_image_con
 The forward is then the t2v trunk behind a stem conv with `in_dim + concat_dim` input channels of which the
 last `concat_dim` see zeros.  The spatial compositions (depthmap / motion / canny / mask / sketch / single_sketch /
 local_image, :294-372, 598-699) each add a `concat_dim`-channel map into that buffer; their stems depend only on
-the conditioning maps, so they are evaluated once per conditioning tensor with torch modules and cached (prompt
+the conditioning maps, so they are evaluated once per conditioning tensor on the C ABI's stem kernels and cached (prompt
 constants ahead of the hot path, like UNetSD_I2VGen's).  'histogram' adds a different context token per FRAME
 (:375-380, 747-755): the trunk then projects K/V per (prompt, frame) — 16 x 78 rows instead of 77 — and the
 cross-attention kernel addresses them frame-major through its strides.  `UNetSD_TFT2V` (unet_tf2tv.py) is the same class without the unused t_w argument.
@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from . import ops
 from .unet import UNetSD_T2VBase, _f32, pack_linear
-from .unet_i2vgen import _FrameTransformer
+from .unet_i2vgen import _FrameTransformer, conv_stack, frame_transformer, mlp_f32
 
 # spatial compositions: composition name -> (forward kwarg, stem attribute, transformer attribute, input channels)
 # (unet_videolcm.py:294-372 / unet_tf2tv.py likewise; every stem is Conv3x3 - SiLU - AdaptiveAvgPool(res/2) -
@@ -74,7 +74,8 @@ class _ComposerTrunk(UNetSD_T2VBase):
             cd = self.context_dim
             self.pre_image_condition = nn.Sequential(nn.Linear(cd, cd), nn.SiLU(), nn.Linear(cd, cd * num_tokens))
         # spatial condition stems: prompt constants (they depend on the conditioning maps only), evaluated once per
-        # conditioning tensor with torch modules and cached — like UNetSD_I2VGen's; registered in the reference's
+        # conditioning tensor on the stem kernels (vgen_conv3x3_small / vgen_adaptive_avgpool2d / vgen_frame_transformer)
+        # and cached — like UNetSD_I2VGen's; the nn.Modules hold the parameters, registered in the reference's
         # order and under its names so stock checkpoints load strict
         c4 = concat_dim * 4
         for name in ("depthmap", "motion", "canny", "mask", "sketch", "single_sketch", "local_image"):
@@ -140,11 +141,8 @@ class _ComposerTrunk(UNetSD_T2VBase):
             return hit[1]
         kwarg, stem, after, cin = _SPATIAL[name]
         Bc, c, F, Hc, Wc = cond.shape
-        z = getattr(self, stem)(cond.float().permute(0, 2, 1, 3, 4).reshape(Bc * F, c, Hc, Wc))     # [(B F), cd, h, w]
-        cd, h, w = z.shape[1:]
-        seq = z.view(Bc, F, cd, h, w).permute(0, 3, 4, 1, 2).reshape(Bc * h * w, F, cd)
-        seq = getattr(self, after)(seq)
-        out = seq.view(Bc, h, w, F, cd).permute(0, 4, 3, 1, 2).contiguous()
+        z = conv_stack(cond.float().permute(0, 2, 1, 3, 4).reshape(Bc * F, c, Hc, Wc).contiguous(), getattr(self, stem))
+        out = frame_transformer(getattr(self, after), z, Bc, F)                    # [B, concat_dim, F, h, w]
         if len(self._stem_cache) >= 32:
             self._stem_cache.clear()
         self._stem_cache[key] = (cond, out)
@@ -168,7 +166,7 @@ class _ComposerTrunk(UNetSD_T2VBase):
             if name not in self.video_compositions:
                 raise ValueError(f"condition '{kwarg}' given but '{name}' is not in video_compositions")
             c = self._spatial_stem(name, cond, B)
-            concat = c if concat is None else concat + c
+            concat = c if concat is None else ops.backend().lincomb4(concat, c, None, None, 1.0, 1.0, 0.0, 0.0)
         unknown = [k for k, v in conds.items() if v is not None and k not in [a[0] for a in _SPATIAL.values()]]
         if unknown:
             raise TypeError(f"{type(self).__name__}.forward: unexpected arguments {unknown}")
@@ -192,7 +190,7 @@ class _ComposerTrunk(UNetSD_T2VBase):
             if hit is not None and hit[0] is histogram:
                 hc = hit[1]
             else:
-                hc = self.hist_context_embedding(histogram.float()).view(B, F, 1, self.context_dim)
+                hc = mlp_f32(histogram.reshape(B * F, -1), self.hist_context_embedding).view(B, F, 1, self.context_dim)
                 self._stem_cache[key] = (histogram, hc)
             # the shared tokens repeated per frame, then this frame's histogram token (:747-755)
             ctx = torch.cat([ctx.unsqueeze(1).expand(B, F, ctx.shape[1], ctx.shape[2]), hc.to(ctx.device)], 2)
