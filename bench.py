@@ -383,10 +383,10 @@ def main():
         del vae
 
     # ---- CPU baseline: the oracle on host cores, bounded sample -------------------------------------------
-    # Sample = the full-size UNetSD_T2VBase (1411 M params) on a 4-frame latent [1,4,4,32,56] — 1/4 of the
-    # 16-frame forward (conv/linear FLOPs are proportional to F) — scaled x4 to one forward, x2 to one
-    # CFG step.  32 threads: more threads made the oracle slower on the 256-core host (363 s per full
-    # forward with 256 threads in an earlier run).
+    # Sample = ONE full forward of the full-size UNetSD_T2VBase (1411 M params) on the whole 16-frame latent
+    # [1,4,16,32,56] — half a CFG step, ~15-20 s on 32 threads; a step is two such forwards.  (r01 timed a 4-frame
+    # latent and scaled by 4: the 5-D GroupNorm / temporal attention do not scale exactly with F.)  32 threads: more
+    # made the oracle slower on the 256-core host (363 s per forward with 256 threads in an earlier run).
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "t2v":
         from oracle import torch_ref
         gold = torch.load(os.path.join(ROOT, "tests", "golden", "unet_t2v_full.pt"), map_location="cpu",
@@ -395,18 +395,16 @@ def main():
         cores = min(os.cpu_count() or 1, 32)
         torch.set_num_threads(cores)
         gen = torch.Generator("cpu").manual_seed(8888)
-        x = torch.randn(1, 4, 16, 32, 56, generator=gen)[:, :, :4].contiguous()
+        x = torch.randn(1, 4, 16, 32, 56, generator=gen)
         yy = torch.randn(1, 77, 1024, generator=gen)
         with torch.no_grad():
             t1 = time.perf_counter()
             torch_ref.unet_forward(sd, x, torch.tensor([981]), yy, 320)
-            cpu_s = time.perf_counter() - t1
-        fwd_s = 4.0 * cpu_s
+            fwd_s = time.perf_counter() - t1
         res["cpu_baseline"] = {"value": round(1.0 / (2 * fwd_s), 5), "unit": "steps/s", "cores": cores,
                                "kind": "port",
-                               "sample": "oracle (oracle/torch_ref.py, fp32) full-size UNet on a 4-frame latent "
-                                         f"[1,4,4,32,56]: {cpu_s:.1f} s, x4 frames x2 CFG branches per step "
-                                         "(extrapolated: 5-D GroupNorm / temporal attention do not scale exactly with F)"}
+                               "sample": "oracle (oracle/torch_ref.py, fp32) full-size UNet, one forward of the 16-frame "
+                                         f"latent [1,4,16,32,56]: {fwd_s:.1f} s; a CFG step is two forwards"}
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

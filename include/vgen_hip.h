@@ -251,10 +251,13 @@ int vgen_linear_f32(const float* x, int32_t n, int32_t K, const float* W, const 
  * (Kpad % 64 == 0, columns (ky*3+kx)*Cin + c, zero padded), so that the 4->320 input conv
  * (unet_t2v.py:112) and the VAE conv_in (autoencoder.py:605) run on the tap-GEMM.
  * Source element (img = bo*Fi + fi, c, y, x) at src + bo*s_bo + fi*s_fi + c*s_c + y*s_y + x*s_x
- * (fp32) — covers both [B,C,F,H,W] latents and [N,H,W,C] maps. */
+ * (fp32) — covers both [B,C,F,H,W] latents and [N,H,W,C] maps.
+ * split = 1: three 9*Cin-column segments [hi | lo | hi] (hi = the 16-bit rounding of the value, lo = the 16-bit rounding
+ * of what it lost; Kpad >= 27*Cin) for weights packed [W_hi | W_hi | W_lo]: the stem conv then sees fp32 inputs and
+ * weights to ~2^-22 at 3x a negligible K. */
 int vgen_im2col3x3_small(const float* src, int64_t nimg, int32_t Fi, int32_t Cin, int32_t H,
                          int32_t W, int64_t s_bo, int64_t s_fi, int64_t s_c, int64_t s_y,
-                         int64_t s_x, void* out, int32_t Kpad, int32_t dtype, void* stream);
+                         int64_t s_x, void* out, int32_t Kpad, int32_t dtype, int32_t split, void* stream);
 
 /* out[p, co] = sum_ci Wm[co, ci] * in[p, ci] + b[co], tiny channel counts (<= 16), fp32.
  * Source/destination addressed with the same (bo, fi, c, y, x) strides as above so the op

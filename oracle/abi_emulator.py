@@ -224,14 +224,20 @@ class EmuBackend:
         s_bo, s_fi, s_c, s_y, s_x = s
         return _strided(t, (nimg // Fi, Fi, C, H, W), (s_bo, s_fi, s_c, s_y, s_x))
 
-    def im2col3x3_small(self, src, nimg, Fi, Cin, H, W, strides, Kpad, dt):
+    def im2col3x3_small(self, src, nimg, Fi, Cin, H, W, strides, Kpad, dt, split=False):
         x = self._view5(src, nimg, Fi, Cin, H, W, strides).reshape(nimg, Cin, H, W)
         xp = torch.nn.functional.pad(x, (1, 1, 1, 1))
-        out = torch.zeros((nimg, H, W, Kpad), dtype=torch.float32)
+        col = torch.zeros((nimg, H, W, 9 * Cin), dtype=torch.float32)
         for tap in range(9):
             ky, kx = tap // 3, tap % 3
-            out[..., tap * Cin:(tap + 1) * Cin] = xp[:, :, ky:ky + H, kx:kx + W].permute(0, 2, 3, 1)
-        return out.reshape(nimg * H * W, Kpad).to(dt)
+            col[..., tap * Cin:(tap + 1) * Cin] = xp[:, :, ky:ky + H, kx:kx + W].permute(0, 2, 3, 1)
+        out = torch.zeros((nimg, H, W, Kpad), dtype=dt)
+        hi = col.to(dt)
+        out[..., : 9 * Cin] = hi
+        if split:                                   # [hi | lo | hi], lo = what the 16-bit rounding lost
+            out[..., 9 * Cin: 18 * Cin] = (col - hi.float()).to(dt)
+            out[..., 18 * Cin: 27 * Cin] = hi
+        return out.reshape(nimg * H * W, Kpad)
 
     def pointwise_small(self, src, nimg, Fi, Cin, H, W, s_strides, Wm, b, Cout, dst, d_strides):
         x = self._view5(src, nimg, Fi, Cin, H, W, s_strides)

@@ -227,7 +227,12 @@ def case_im2col(be, dev, dt, layout, seed=0):
         nimg, Fi = n, 1
     ref = EMU.im2col3x3_small(src, nimg, Fi, C, H, W, s, 64, dt)
     out = be.im2col3x3_small(src.to(dev), nimg, Fi, C, H, W, s, 64, dt)
-    return {"col": stats(out, ref)}
+    # split layout [hi | lo | hi]: must be the emulator's bits (the lo segment is an exact fp32 subtraction)
+    ref3 = EMU.im2col3x3_small(src, nimg, Fi, C, H, W, s, 128, dt, split=True)
+    out3 = be.im2col3x3_small(src.to(dev), nimg, Fi, C, H, W, s, 128, dt, split=True)
+    r = stats(out3, ref3)
+    r["finite"] = r["finite"] and bool(torch.equal(out3.cpu().view(torch.int16), ref3.view(torch.int16)))
+    return {"col": stats(out, ref), "col_split": r}
 
 
 def case_pointwise(be, dev, seed=0):

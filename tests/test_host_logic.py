@@ -318,6 +318,9 @@ def test_vae_attention_query_blocks(emu_backend):
     v.load_state_dict(torch_ref.synth_state_dict(g["shapes"], seed=g["seed"]), strict=True)
     one = v.decode(g["z"])
     v._attn_qb = 12                                        # hw = 32 -> blocks of 12, 12, 8 queries
-    assert rel_l2(v.decode(g["z"]), one) < 1e-6
+    # the CPU BLAS sums a 12-row block in a different order than the 32-row one; where that flips a 16-bit rounding
+    # the difference is amplified to the rounding-noise floor downstream (on the GPU the per-row sums do not depend on
+    # the block: tests/test_gpu_model.py::test_vae_odd_frame_vs_reference_golden asserts 1e-6 there)
+    assert rel_l2(v.decode(g["z"]), one) < 2e-3
     with pytest.raises(NotImplementedError):
         AutoencoderKL(ddconfig=g["ddconfig"], embed_dim=8)

@@ -117,18 +117,23 @@ __device__ __forceinline__ int64_t src_off(const SrcGeom& g, int64_t img, int c,
 // the threads with tap >= 9.
 template <typename T>
 __global__ __launch_bounds__(256) void im2col3x3_small_kernel(const float* __restrict__ src,
-                                                              SrcGeom g, int64_t M, int Kpad,
+                                                              SrcGeom g, int64_t M, int Kpad, int split,
                                                               uint16_t* __restrict__ out) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int slots = (Kpad + g.C - 1) / g.C;  // taps + padding slots of C columns
   const int64_t m = idx / slots;
-  const int tap = (int)(idx - m * slots);
+  const int ptap = (int)(idx - m * slots);
   if (m >= M) return;
+  // split: three segments of 9 taps — [hi | lo | hi] with hi = round16(v), lo = round16(v - hi) — against weights packed
+  // [W_hi | W_hi | W_lo]: x*W = x_hi*W_hi + x_lo*W_hi + x_hi*W_lo to ~2^-22, i.e. the 4- / 3-channel stem conv sees
+  // its fp32 input and fp32 weights (the latent's 16-bit rounding was 2.4e-4 of the UNet's 1.37e-3)
+  const int seg = split ? ptap / 9 : 0;
+  const int tap = split ? (seg < 3 ? ptap - seg * 9 : 9) : ptap;
   const int hw = g.H * g.W;
   const int64_t img = m / hw;
   const int rem = (int)(m - img * hw);
   const int y = rem / g.W, x = rem - y * g.W;
-  uint16_t* o = out + m * Kpad + tap * g.C;
+  uint16_t* o = out + m * Kpad + ptap * g.C;
   bool inb = false;
   int iy = 0, ix = 0;
   if (tap < 9) {
@@ -137,10 +142,12 @@ __global__ __launch_bounds__(256) void im2col3x3_small_kernel(const float* __res
     inb = iy >= 0 && iy < g.H && ix >= 0 && ix < g.W;
   }
   for (int c = 0; c < g.C; ++c) {
-    if (tap * g.C + c >= Kpad) break;
+    if (ptap * g.C + c >= Kpad) break;
     float v = 0.f;
     if (inb) v = src[src_off(g, img, c, iy, ix)];
-    o[c] = T::from_f32(v);
+    uint16_t hi = T::from_f32(v);
+    if (seg == 1) hi = T::from_f32(v - T::to_f32(hi));
+    o[c] = hi;
   }
 }
 
@@ -322,9 +329,10 @@ extern "C" int vgen_embed_tokens(const int64_t* tokens, int64_t rows, int32_t L,
 extern "C" int vgen_im2col3x3_small(const float* src, int64_t nimg, int32_t Fi, int32_t Cin,
                                     int32_t H, int32_t W, int64_t s_bo, int64_t s_fi, int64_t s_c,
                                     int64_t s_y, int64_t s_x, void* out, int32_t Kpad,
-                                    int32_t dtype, void* stream) {
+                                    int32_t dtype, int32_t split, void* stream) {
   VGEN_REQUIRE(dtype == VGEN_BF16 || dtype == VGEN_F16, "im2col: dtype");
-  VGEN_REQUIRE(Cin > 0 && Cin <= 16 && Kpad % 64 == 0 && Kpad >= 9 * Cin && Fi > 0,
+  VGEN_REQUIRE(split == 0 || split == 1, "im2col: split");
+  VGEN_REQUIRE(Cin > 0 && Cin <= 16 && Kpad % 64 == 0 && Kpad >= (split ? 27 : 9) * Cin && Fi > 0,
                "im2col: Cin=%d Kpad=%d", Cin, Kpad);
   const SrcGeom g{Fi, Cin, H, W, s_bo, s_fi, s_c, s_y, s_x};
   const int64_t M = nimg * H * W;
@@ -336,10 +344,10 @@ extern "C" int vgen_im2col3x3_small(const float* src, int64_t nimg, int32_t Fi, 
   hipStream_t s = (hipStream_t)stream;
   if (dtype == VGEN_BF16)
     hipLaunchKernelGGL(im2col3x3_small_kernel<BF16>, dim3((unsigned)grid), dim3(256), 0, s, src, g,
-                       M, Kpad, (uint16_t*)out);
+                       M, Kpad, split, (uint16_t*)out);
   else
     hipLaunchKernelGGL(im2col3x3_small_kernel<F16>, dim3((unsigned)grid), dim3(256), 0, s, src, g,
-                       M, Kpad, (uint16_t*)out);
+                       M, Kpad, split, (uint16_t*)out);
   return vgen_check_launch("im2col3x3_small");
 }
 

@@ -80,7 +80,7 @@ SYMBOLS = {
     "vgen_embed_tokens": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "vgen_linear_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "vgen_im2col3x3_small": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64,
-                                       _i64, _vp, _i32, _i32, _vp]),
+                                       _i64, _vp, _i32, _i32, _i32, _vp]),
     "vgen_pointwise_small": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64,
                                        _i64, _vp, _vp, _i32, _vp, _i64, _i64, _i64, _i64, _i64,
                                        _vp]),

@@ -350,11 +350,11 @@ class HipBackend:
         _lib.check(rc, "vgen_timestep_embedding")
         return out
 
-    def im2col3x3_small(self, src, nimg, Fi, Cin, H, W, strides, Kpad, dt):
+    def im2col3x3_small(self, src, nimg, Fi, Cin, H, W, strides, Kpad, dt, split=False):
         assert src.dtype == torch.float32
         out = torch.empty((nimg * H * W, Kpad), dtype=dt, device=src.device)
         rc = self.lib.vgen_im2col3x3_small(_ptr(src), nimg, Fi, Cin, H, W, *strides, _ptr(out), Kpad,
-                                           _ENUM[dt], self._stream(src))
+                                           _ENUM[dt], int(bool(split)), self._stream(src))
         _lib.check(rc, "vgen_im2col3x3_small")
         return out
 

@@ -167,11 +167,17 @@ def pack_geglu(w: torch.Tensor, b: torch.Tensor, dt):
     return w.detach()[perm].to(dt).contiguous(), b.detach()[perm].float().contiguous()
 
 
-def pack_small_conv3x3(w: torch.Tensor, kpad: int, dt) -> torch.Tensor:
-    """[Cout, Cin<=7, 3, 3] -> [Cout, kpad] matching vgen_im2col3x3_small column order."""
-    p = w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+def pack_small_conv3x3(w: torch.Tensor, kpad: int, dt, split: bool = False) -> torch.Tensor:
+    """[Cout, Cin<=16, 3, 3] -> [Cout, kpad] matching vgen_im2col3x3_small column order; split: [W_hi | W_hi | W_lo]
+    against the operand's [hi | lo | hi] segments (the stem conv at fp32 precision, 3x a negligible K)."""
+    p = w.detach().float().permute(0, 2, 3, 1).reshape(w.shape[0], -1)
     out = torch.zeros((w.shape[0], kpad), dtype=dt, device=w.device)
-    out[:, : p.shape[1]] = p.to(dt)
+    k = p.shape[1]
+    hi = p.to(dt)
+    out[:, :k] = hi
+    if split:
+        out[:, k: 2 * k] = hi
+        out[:, 2 * k: 3 * k] = (p - hi.float()).to(dt)
     return out
 
 
@@ -334,13 +340,13 @@ class UNetSD_T2VBase(nn.Module):
 
         conv_in = self.input_blocks[0][0]
         cin0 = self._stem_channels()
-        self._kpad_in = ((9 * cin0 + 63) // 64) * 64
+        self._kpad_in = ((27 * cin0 + 63) // 64) * 64          # split stem: [hi | lo | hi] segments
         if cin0 % 64 == 0:
             P["conv_in"] = (pack_conv3x3(conv_in.weight, dt), _f32(conv_in.bias))
         else:
             if cin0 > 16:
                 raise NotImplementedError("stem conv input channels must be <= 16 or a multiple of 64")
-            P["conv_in"] = (pack_small_conv3x3(conv_in.weight, self._kpad_in, dt), _f32(conv_in.bias))
+            P["conv_in"] = (pack_small_conv3x3(conv_in.weight, self._kpad_in, dt, split=True), _f32(conv_in.bias))
 
         def pack_res(rb: _ResBlockP):
             d = {}
@@ -643,7 +649,7 @@ class UNetSD_T2VBase(nn.Module):
         if C % 64 == 0:
             raise NotImplementedError("wide input stems are not on the t2v path")
         sFHW = F * H * W
-        col = be.im2col3x3_small(x, B * F, F, C, H, W, (C * sFHW, H * W, sFHW, W, 1), self._kpad_in, dt)
+        col = be.im2col3x3_small(x, B * F, F, C, H, W, (C * sFHW, H * W, sFHW, W, 1), self._kpad_in, dt, split=True)
         h = self._linear(col, P["conv_in"], B * F * H * W, colstats=True)
 
         def run(mod, h, x2, H, W):

@@ -227,8 +227,8 @@ class AutoencoderKL(nn.Module):
         for side in ("encoder", "decoder"):
             net = getattr(self, side)
             ci = net.conv_in
-            kpad = ((9 * ci.in_channels + 63) // 64) * 64
-            P[side + ".conv_in"] = (pack_small_conv3x3(ci.weight, kpad, dt), _f32(ci.bias), kpad)
+            kpad = ((27 * ci.in_channels + 63) // 64) * 64          # split stem: fp32-accurate input / weights
+            P[side + ".conv_in"] = (pack_small_conv3x3(ci.weight, kpad, dt, split=True), _f32(ci.bias), kpad)
             P[side + ".norm_out"] = (_f32(net.norm_out.weight), _f32(net.norm_out.bias))
             P[side + ".conv_out"] = (pack_conv3x3(net.conv_out.weight, dt), _f32(net.conv_out.bias))
         for nm in ("quant_conv", "post_quant_conv"):
@@ -303,7 +303,7 @@ class AutoencoderKL(nn.Module):
     def _stem(self, side, src, n, Cin, H, W, strides):
         be, dt = ops.backend(), self.compute_dtype
         Wc, bc, kpad = self._packed[side + ".conv_in"]
-        col = be.im2col3x3_small(src, n, 1, Cin, H, W, strides, kpad, dt)
+        col = be.im2col3x3_small(src, n, 1, Cin, H, W, strides, kpad, dt, split=True)
         return be.tapgemm(TapGemm(A=col, W=Wc, M=n * H * W, N=Wc.shape[0], C1=kpad, bias=bc))
 
     # -- public API ----------------------------------------------------------------------------------
