@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libvgen_hip.so")
+# VGEN_HIP_LIB: load another build of the library instead (same-box A/B of two kernel versions; tuning switch)
+LIB_PATH = os.environ.get("VGEN_HIP_LIB") or os.path.join(HERE, "libvgen_hip.so")
 
 VGEN_BF16, VGEN_F16, VGEN_F32 = 0, 1, 2
 TAP_LINEAR, TAP_CONV3X3, TAP_TEMPORAL3 = 0, 1, 2
