@@ -159,6 +159,9 @@ def main():
                          "gather/update) even at --gpus 1")
     ap.add_argument("--vae-size", default="256x448", help="HxW of the decoded frame")
     ap.add_argument("--dump-shapes", action="store_true", help="write per-shape kernel timings to gpurun_out/")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for --gpus > 1 (nccl = RCCL).  gloo + VGEN_BENCH_ONE_DEVICE=1 runs all "
+                         "ranks on cuda:0: a functional test of the multi-rank code path on a 1-GPU box, not a measurement")
     args = ap.parse_args()
     if args.no_graph:
         os.environ["VGEN_GRAPH"] = "0"
@@ -172,10 +175,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local)
+    one_dev = os.environ.get("VGEN_BENCH_ONE_DEVICE") == "1"
+    dev = torch.device("cuda", 0 if one_dev else local)
     torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     ops.set_backend(None)
     assert ops.backend().name == "hip"
@@ -252,7 +259,8 @@ def main():
         "config": {"workload": cfg["desc"], "name": args.config,
                    "prompts_in_flight": P, "units_per_step": G * P,
                    "api": "DiffusionDDIM.ddim_sample per step (public sampler API; cached sampling session underneath)",
-                   "parallelism": "single GPU" if world == 1 else f"unit partition over {world} ranks, 1 all-gather/step",
+                   "parallelism": "single GPU" if world == 1 else
+                   f"unit partition over {world} ranks, 1 all-gather/step ({args.backend}{', all ranks on one device: functional test' if one_dev else ''})",
                    "hipgraph": bool(sess is not None and sess.use_graph and sess._graphs) and
                    ("whole step" if part is None else "local units' forward")},
         "finite": finite, "latent_absmax_after_timed_steps": xt_absmax,
@@ -408,6 +416,7 @@ def main():
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:
+        dist.barrier()                      # rank 0 ran the untimed extras (roofline pass, VAE); leave together
         dist.destroy_process_group()
 
 
