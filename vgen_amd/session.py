@@ -86,6 +86,9 @@ class UnitSession:
         self.Lctx = ctx.shape[1]
         self.kv = model._context_kv(ctx.contiguous(), self.device) if nU else None   # prompt constant: once
         self.fps = None if prep["fps"] is None else prep["fps"].to(self.device)[idx].contiguous()
+        # classifier-free guidance: the G sets share the latent; when their stem channels / fps agree too, the layers
+        # ahead of the first cross-attention are evaluated once (UNetSD_T2VBase._body, shared_groups)
+        self.shared = model.shared_prefix_groups(prep, self.G, self.B) if self.full else 1
         self.t_units = torch.zeros((nU,), dtype=t_dtype, device=self.device)
         self.out = torch.empty((nU, model.out_dim, self.F, self.H, self.W), dtype=torch.float32, device=self.device)
         # time-embedding table: integer timesteps of a known schedule length, no fps term inside the SiLU
@@ -122,7 +125,7 @@ class UnitSession:
             emb = self.emb_tab.index_select(0, self.t_units)
         else:
             emb = m._embed(self.t_units, self.fps, nU, self.device)
-        m._body(self.x_units, emb, self.kv, self.Lctx, self.per_frame, out=self.out)
+        m._body(self.x_units, emb, self.kv, self.Lctx, self.per_frame, out=self.out, shared_groups=self.shared)
 
     def _run(self, key, launches):
         """Run `launches()` eagerly (first call: warms the allocator, JIT-free) and from then on as a graph."""

@@ -17,6 +17,7 @@ here; `forward` never calls torch compute ops on activations.
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -567,8 +568,23 @@ class UNetSD_T2VBase(nn.Module):
         xs = x.float().repeat(G, 1, 1, 1, 1)
         if prep["extra"] is not None:
             xs = torch.cat([xs, prep["extra"]], 1)
-        out = self._trunk(xs, t.repeat(G), prep["ctx"], prep["fps"], ctx_per_frame=prep["per_frame"])
+        out = self._trunk(xs, t.repeat(G), prep["ctx"], prep["fps"], ctx_per_frame=prep["per_frame"],
+                          shared_groups=self.shared_prefix_groups(prep, G, x.shape[0]))
         return tuple(out.chunk(G, 0))
+
+    @staticmethod
+    def shared_prefix_groups(prep, G, B):
+        """G when the G kwarg sets feed IDENTICAL stem inputs (same latent by construction, same extra stem channels,
+        same fps) — then everything ahead of the first cross-attention is the same computation for every set and
+        `_body` evaluates it once (the cond / uncond pair of classifier-free guidance differs only in its context)."""
+        if G <= 1 or os.environ.get("VGEN_SHARED_PREFIX", "1") == "0":
+            return 1
+        ex, fps = prep["extra"], prep["fps"]
+        if ex is not None and not all(torch.equal(ex[:B], ex[g * B:(g + 1) * B]) for g in range(1, G)):
+            return 1
+        if fps is not None and not all(torch.equal(fps[:B], fps[g * B:(g + 1) * B]) for g in range(1, G)):
+            return 1
+        return G
 
     @torch.no_grad()
     def forward(self, x, t, y=None, fps=None, masked=None, video_mask=None, focus_present_mask=None,
@@ -623,7 +639,7 @@ class UNetSD_T2VBase(nn.Module):
         ctx16 = be.act_cast(ctx.to(device=dev, dtype=torch.float32).reshape(nctx * Lctx, -1).contiguous(), 0, dt)
         return self._linear(ctx16, self._packed["kv_all"], nctx * Lctx, out_dtype=dt)
 
-    def _trunk(self, x, t, ctx, fps=None, ctx_per_frame=False):
+    def _trunk(self, x, t, ctx, fps=None, ctx_per_frame=False, shared_groups=1):
         """Embeddings + encoder / middle / decoder / head on rows (unet_t2v.py:241-277).  `x` carries every
         input channel of the stem conv ([B, C, F, H, W]), `ctx` every cross-attention token: [B, L, 1024] shared
         by the frames of a video, or [B * F, L, 1024] with ctx_per_frame (frame-major per prompt)."""
@@ -633,10 +649,16 @@ class UNetSD_T2VBase(nn.Module):
         assert ctx.shape[0] == (B * F if ctx_per_frame else B), (tuple(ctx.shape), B, F, ctx_per_frame)
         emb_all = self._embed(t, fps, B, x.device)
         kv_all = self._context_kv(ctx, x.device)
-        return self._body(x, emb_all, kv_all, ctx.shape[1], ctx_per_frame)
+        return self._body(x, emb_all, kv_all, ctx.shape[1], ctx_per_frame, shared_groups=shared_groups)
 
-    def _body(self, x, emb_all, kv_all, Lctx, ctx_per_frame=False, out=None):
-        """Stem conv, encoder / middle / decoder, head: rows in, [B, out_dim, F, H, W] fp32 out (into `out`)."""
+    def _body(self, x, emb_all, kv_all, Lctx, ctx_per_frame=False, out=None, shared_groups=1):
+        """Stem conv, encoder / middle / decoder, head: rows in, [B, out_dim, F, H, W] fp32 out (into `out`).
+
+        shared_groups = G > 1: the B units are G groups (group-major) with IDENTICAL stem inputs and row biases — the
+        cond / uncond pair of classifier-free guidance, which differ only in their context.  Everything ahead of the
+        first cross-attention (stem conv, the first TemporalTransformer, the first ResBlock incl. its temporal convs:
+        ~7 % of a forward) is then evaluated ONCE on B/G units and its rows replicated; the reference runs it per
+        branch (diffusion_ddim.py:157-158)."""
         be = ops.backend()
         dt = self.compute_dtype
         P = self._packed
@@ -644,38 +666,61 @@ class UNetSD_T2VBase(nn.Module):
         assert C == self._stem_channels()
         dev = x.device
         x = x.float().contiguous()
+        G = int(shared_groups)
+        first = self.input_blocks[1] if len(self.input_blocks) > 1 else None
+        if G > 1 and not (B % G == 0 and isinstance(first, nn.ModuleList) and isinstance(first[0], _ResBlockP)):
+            G = 1
+        Bp = B // G                                          # units in the shared prefix
 
         # input conv: im2col of the [B,C,F,H,W] latent straight into rows
         if C % 64 == 0:
             raise NotImplementedError("wide input stems are not on the t2v path")
         sFHW = F * H * W
-        col = be.im2col3x3_small(x, B * F, F, C, H, W, (C * sFHW, H * W, sFHW, W, 1), self._kpad_in, dt, split=True)
-        h = self._linear(col, P["conv_in"], B * F * H * W, colstats=True)
+        col = be.im2col3x3_small(x[:Bp], Bp * F, F, C, H, W, (C * sFHW, H * W, sFHW, W, 1), self._kpad_in, dt, split=True)
+        h = self._linear(col, P["conv_in"], Bp * F * H * W, colstats=True)
 
-        def run(mod, h, x2, H, W):
+        def run(mod, h, x2, H, W, nB=B):
             if isinstance(mod, _ResBlockP):
-                return self._resblock(mod, h, x2, emb_all, B, F, H, W), H, W
+                return self._resblock(mod, h, x2, emb_all, nB, F, H, W), H, W
             assert x2 is None
             if isinstance(mod, _SpatialTransformerP):
-                return self._spatial_tx(mod, h, kv_all, B, F, H, W, Lctx, ctx_per_frame), H, W
+                return self._spatial_tx(mod, h, kv_all, nB, F, H, W, Lctx, ctx_per_frame), H, W
             if isinstance(mod, _TemporalTransformerP):
-                return self._temporal_tx(mod, h, B, F, H, W), H, W
+                return self._temporal_tx(mod, h, nB, F, H, W), H, W
             if isinstance(mod, _DownP):
                 a = be.act_cast(h, 0, dt)
-                o, Ho, Wo = self._conv3x3(a, P[mod._pname], B * F, H, W, h.shape[1], stride=2, pad=mod.pad,
+                o, Ho, Wo = self._conv3x3(a, P[mod._pname], nB * F, H, W, h.shape[1], stride=2, pad=mod.pad,
                                           colstats=True)
                 return o, Ho, Wo
             if isinstance(mod, _UpP):
                 a = be.act_cast(h, 0, dt)
-                o, Ho, Wo = self._conv3x3(a, P[mod._pname], B * F, H, W, h.shape[1], ups=1, crop=mod.crop,
+                o, Ho, Wo = self._conv3x3(a, P[mod._pname], nB * F, H, W, h.shape[1], ups=1, crop=mod.crop,
                                           colstats=True)
                 return o, Ho, Wo
             raise TypeError(type(mod))
 
+        def replicate(t):
+            """rows of the Bp shared units -> rows of all B units (group-major), producer statistics included"""
+            if G == 1:
+                return t
+            r = t.repeat(G, 1)
+            cs = ops.colstats_of(t, t.shape[0])
+            if cs is not None and t.shape[0] % ops.CS_ROWS == 0:
+                r.vgen_cs = cs.repeat(G, 1, 1)
+            return r
+
         xs = []
-        h, _, _ = run(self.input_blocks[0][1], h, None, H, W)
-        xs.append((h, H, W))
-        for blk in list(self.input_blocks)[1:]:
+        h, _, _ = run(self.input_blocks[0][1], h, None, H, W, Bp)
+        xs.append((replicate(h), H, W))
+        rest = list(self.input_blocks)[1:]
+        if G > 1:
+            h, H, W = run(first[0], h, None, H, W, Bp)      # the first ResBlock: still no context involved
+            h = replicate(h)
+            for m in list(first)[1:]:
+                h, H, W = run(m, h, None, H, W)
+            xs.append((h, H, W))
+            rest = rest[1:]
+        for blk in rest:
             mods = list(blk) if isinstance(blk, nn.ModuleList) else [blk]
             for m in mods:
                 h, H, W = run(m, h, None, H, W)
