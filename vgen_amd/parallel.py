@@ -9,8 +9,9 @@ CFG + DDIM update redundantly for all prompts.  The reference has no such path (
 the whole prompt list: tools/inferences/inference_text2video_entrance.py:93,165-171); this is the
 design the north-star asks for.
 
-unit u = p * G + g  ->  rank u % W.  One process per GPU; torch.distributed supplies the
-process group (backend "nccl" == RCCL on ROCm, "gloo" in the CPU tests).
+unit u = p * G + g  ->  rank u % W, or — when every rank can own whole prompts (P % W == 0) — rank (u // G) % W.
+One process per GPU; torch.distributed supplies the process group (backend "nccl" == RCCL on ROCm, "gloo" in the
+CPU tests).
 
 The local units run through a sampling session (vgen_amd/session.py): their condition stems and K/V are
 prompt constants computed once, and the local UNet batch is one hipGraph replay that writes straight into
@@ -43,24 +44,41 @@ class UnitPartition:
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         from .session import SessionCache
         self.sessions = SessionCache()
+        self._sub = {}              # (kwargs identity, local prompts) -> per-rank slices of the kwarg sets
 
-    # -- static helpers --------------------------------------------------------------------------
-    def owner(self, u: int) -> int:
-        return u % self.world
+    # -- unit -> (rank, slot) ----------------------------------------------------------------------
+    # unit u = p * G + g.  Two layouts:
+    #   'unit'   (default)            owner u % W, slot u // W — the CFG pair of ONE prompt lands on two ranks (P = 1,
+    #                                 W = 2 is the north-star's "cond on GPU 0, uncond on GPU 1");
+    #   'prompt' (when P % W == 0)    owner (u // G) % W — a rank owns whole prompts, so its local batch is an ordinary
+    #                                 CFG batch and shares the context-independent prefix between the branches
+    #                                 (UNetSD_T2VBase._body shared_groups); slot = g * (P / W) + p // W, i.e. the
+    #                                 session's own group-major order: its output buffer IS the all-gather payload.
+    def layout(self, P: int, G: int) -> str:
+        return "prompt" if (G > 1 and P % self.world == 0) else "unit"
 
-    def my_units(self, U: int) -> List[int]:
-        return [u for u in range(U) if self.owner(u) == self.rank]
+    def owner(self, u: int, P: int = 0, G: int = 1) -> int:
+        return (u // G) % self.world if P and self.layout(P, G) == "prompt" else u % self.world
+
+    def slot(self, u: int, P: int = 0, G: int = 1) -> int:
+        if P and self.layout(P, G) == "prompt":
+            return (u % G) * (P // self.world) + (u // G) // self.world
+        return u // self.world
+
+    def my_units(self, U: int, P: int = 0, G: int = 1) -> List[int]:
+        mine = [u for u in range(U) if self.owner(u, P, G) == self.rank]
+        return sorted(mine, key=lambda u: self.slot(u, P, G))
 
     def slots(self, U: int) -> int:
         return (U + self.world - 1) // self.world
 
     # -- the per-step exchange -----------------------------------------------------------------------
-    def gather_stacked(self, mine: torch.Tensor, U: int) -> List[torch.Tensor]:
-        """`mine`: [len(my_units(U)), ...] outputs of this rank's units in order.  Returns the U unit outputs on
+    def gather_stacked(self, mine: torch.Tensor, U: int, P: int = 0, G: int = 1) -> List[torch.Tensor]:
+        """`mine`: [len(my_units), ...] outputs of this rank's units in slot order.  Returns the U unit outputs on
         every rank after ONE all-gather."""
         S = self.slots(U)
         if self.world == 1:
-            return [mine[i] for i in range(U)]
+            return [mine[self.slot(u, P, G)] for u in range(U)]
         if mine.shape[0] == S and mine.is_contiguous():
             buf = mine
         else:                                                   # ragged tail: this rank owns fewer than S units
@@ -68,11 +86,10 @@ class UnitPartition:
             buf[: mine.shape[0]].copy_(mine)
         allb = mine.new_empty((self.world * S,) + tuple(mine.shape[1:]))
         dist.all_gather_into_tensor(allb, buf, group=self.group)
-        # unit u sits in rank (u % W)'s slot (u // W)
-        return [allb[(u % self.world) * S + (u // self.world)] for u in range(U)]
+        return [allb[self.owner(u, P, G) * S + self.slot(u, P, G)] for u in range(U)]
 
     def gather_units(self, mine: Sequence[torch.Tensor], U: int, like: torch.Tensor) -> List[torch.Tensor]:
-        """List form of gather_stacked (each element shaped like `like`)."""
+        """List form of gather_stacked, 'unit' layout (each element shaped like `like`)."""
         if len(mine):
             st = torch.stack(list(mine))
         else:
@@ -80,24 +97,47 @@ class UnitPartition:
         return self.gather_stacked(st, U)
 
     # -- classifier-free guidance for P prompts stacked in the batch dim ---------------------------------
+    def _local_kwargs(self, model_kwargs, ps, P, device):
+        """The kwarg sets restricted to the local prompts `ps` — built once per (kwargs identity, ps) so that the
+        sampling session keyed on tensor identity is found again on every step."""
+        from .session import _kw_key
+        key = (_kw_key(model_kwargs), tuple(ps))
+        hit = self._sub.get(key)
+        if hit is None:
+            idx = torch.tensor(ps, dtype=torch.long, device=device)
+            hit = (idx, [_slice_kwargs(kw, idx, P) for kw in model_kwargs], [dict(kw) for kw in model_kwargs])
+            if len(self._sub) >= 4:
+                self._sub.clear()
+            self._sub[key] = hit
+        return hit[0], hit[1]
+
     def run_units(self, model, xt, t, model_kwargs, num_timesteps=None):
         """xt [P, C, F, H, W], t [P], model_kwargs = list of G kwarg sets whose tensors are stacked over the P
         prompts along dim 0.  Returns G tensors [P, out_dim, F, H, W], identical on every rank."""
         G = len(model_kwargs)
         P = xt.shape[0]
         U = P * G
-        mine = self.my_units(U)
+        mine = self.my_units(U, P, G)
         out_dim = getattr(model, "out_dim", xt.shape[1])
         unit_shape = (out_dim,) + tuple(xt.shape[2:])
-        # a vgen_amd model: session over the local units (session index g * P + p); tables only for long t
-        sess = None
-        if xt.dim() == 5 and hasattr(model, "_prepare_units"):
-            nt = num_timesteps if t.dtype == torch.long else None
+        is_unit_model = xt.dim() == 5 and hasattr(model, "_prepare_units")
+        nt = num_timesteps if t.dtype == torch.long else None
+        local = None
+        if is_unit_model and self.layout(P, G) == "prompt":
+            # whole prompts per rank: an ordinary CFG session over the local prompts
+            ps = sorted({u // G for u in mine})
+            idx, sub = self._local_kwargs(model_kwargs, ps, P, xt.device)
+            sess = self.sessions.get(model, (len(ps),) + tuple(xt.shape[1:]), xt.device, sub, t.dtype, nt)
+            if sess is not None:
+                sess.eval(xt.index_select(0, idx), t.index_select(0, idx))
+                local = sess.out                                               # [G * len(ps), ...] = slot order
+        if local is None and is_unit_model:
+            # session over the local units (session index g * P + p)
             sess = self.sessions.get(model, tuple(xt.shape), xt.device, list(model_kwargs), t.dtype, nt,
                                      units=[(u % G) * P + (u // G) for u in mine])
-        if sess is not None:
-            local = sess.eval(xt, t)                                       # [len(mine), out_dim, F, H, W]
-        else:
+            if sess is not None:
+                local = sess.eval(xt, t)                                       # [len(mine), out_dim, F, H, W]
+        if local is None:
             outs = {}
             for g in range(G):
                 ps = [u // G for u in mine if u % G == g]
@@ -109,5 +149,5 @@ class UnitPartition:
                     outs[p * G + g] = o[i].float()
             local = torch.stack([outs[u] for u in mine]) if mine else \
                 xt.new_zeros((0,) + unit_shape, dtype=torch.float32)
-        allu = self.gather_stacked(local, U)
+        allu = self.gather_stacked(local, U, P, G)
         return tuple(torch.stack([allu[p * G + g] for p in range(P)]) for g in range(G))

@@ -101,6 +101,7 @@ class UnitSession:
         self.xt_1 = torch.empty((self.B, self.C_lat, self.F, self.H, self.W), dtype=torch.float32, device=self.device)
         self.x0 = torch.empty_like(self.xt_1)
         self._last_out = None       # the tensor handed to the caller by the previous fused step
+        self._bidx = None
 
     # -- inputs --------------------------------------------------------------------------------------
     def load(self, xt, t):
@@ -112,9 +113,10 @@ class UnitSession:
                 self.x_units.view(self.G, self.B, *self.x_units.shape[1:])[:, :, :self.C_lat].copy_(xt)
             self.t_units.view(self.G, self.B).copy_(t.to(self.t_units.dtype))
         else:
-            b = torch.tensor([u % self.B for u in self.units], device=self.device)
-            self.x_units[:, :self.C_lat].copy_(xt.float()[b])
-            self.t_units.copy_(t.to(self.t_units.dtype)[b])
+            if self._bidx is None:                  # prompt index of every local unit (built once: no per-step H2D copy)
+                self._bidx = torch.tensor([u % self.B for u in self.units], dtype=torch.long, device=self.device)
+            self.x_units[:, :self.C_lat].copy_(xt.float().index_select(0, self._bidx))
+            self.t_units.copy_(t.to(self.t_units.dtype).index_select(0, self._bidx))
         self._last_out = None
 
     # -- launch sequences ----------------------------------------------------------------------------
