@@ -474,41 +474,53 @@ class UNetSD_T2VBase(nn.Module):
         # FF output is only consumed by proj_out -> emit it 16-bit (sum formed in fp32)
         return self._linear(g, P["ff2"], M, residual=x, out_dtype=dt)
 
-    def _spatial_tx(self, st: _SpatialTransformerP, x, kv_all, B, F, H, W, Lctx, kv_per_frame=False):
-        """reference: SpatialTransformer.forward (util.py:354-373)."""
+    def _spatial_tx(self, st: _SpatialTransformerP, x, kv_all, B, F, H, W, Lctx, kv_per_frame=False, share=1,
+                    replicate=None):
+        """reference: SpatialTransformer.forward (util.py:354-373) around BasicTransformerBlock.forward (:700-704).
+
+        share = G > 1: `x` holds the rows of B / G units whose G context variants still share everything — GroupNorm,
+        proj_in, the whole self-attention branch and the cross-attention's QUERY projection do not see the context, so
+        they run once; `replicate` then fans the token stream, the queries and x out to all B units where the
+        cross-attention starts (see _body, shared_groups)."""
         be = ops.backend()
         dt = self.compute_dtype
         P = self._packed[st._pname]
+        T = P["tb"]
         N = H * W
         M = B * F * N
         d, heads = st.inner, st.heads
-        a, _ = be.groupnorm(x, None, B * F, N, 32, 1e-6, *P["gn"], False, False, dt)
-        tok = self._linear(a, P["pin"], M)
+        Bp = B // share
+        Mp = Bp * F * N
         scale = HEAD_DIM ** -0.5
-
-        def attn1(qkv):
-            out = torch.empty((M, d), dtype=dt, device=qkv.device)
-            ld = 3 * d
-            return be.attention(Attn(q=qkv, k=qkv[:, d:], v=qkv[:, 2 * d:], out=out, heads=heads,
-                                     nq=N, nk=N, nbatch=B * F, inner=1,
-                                     q_s=(ld, N * ld, 0), k_s=(ld, N * ld, 0), v_s=(ld, N * ld, 0),
-                                     o_s=(d, N * d, 0), scale=scale))
-
-        def attn2(n):
-            q = self._linear(n, P["tb"]["q2"], M, out_dtype=dt)
-            out = torch.empty((M, d), dtype=dt, device=q.device)
-            kw = kv_all.shape[1]
-            k = kv_all[:, st._kv_off: st._kv_off + d]
-            v = kv_all[:, st._kv_off + d: st._kv_off + 2 * d]
-            # K/V rows are per prompt (every frame of a video reads the same 77 context rows: no x F repeat,
-            # unet_t2v.py:255) or, when a composition adds a per-frame token (histogram), per (prompt, frame)
-            kvs = (kw, F * Lctx * kw, Lctx * kw) if kv_per_frame else (kw, Lctx * kw, 0)
-            return be.attention(Attn(q=q, k=k, v=v, out=out, heads=heads, nq=N, nk=Lctx,
-                                     nbatch=B * F, inner=F,
-                                     q_s=(d, F * N * d, N * d), k_s=kvs,
-                                     v_s=kvs, o_s=(d, F * N * d, N * d), scale=scale))
-
-        t = self._tblock(P["tb"], tok, M, d, heads, attn1, attn2)
+        a, _ = be.groupnorm(x, None, Bp * F, N, 32, 1e-6, *P["gn"], False, False, dt)
+        tok = self._linear(a, P["pin"], Mp)
+        # x = x + attn1(norm1(x))
+        n = be.layernorm(tok, *T["ln1"], 1e-5, dt)
+        qkv = self._linear(n, T["qkv1"], Mp, out_dtype=dt)
+        o = torch.empty((Mp, d), dtype=dt, device=qkv.device)
+        ld = 3 * d
+        be.attention(Attn(q=qkv, k=qkv[:, d:], v=qkv[:, 2 * d:], out=o, heads=heads, nq=N, nk=N, nbatch=Bp * F, inner=1,
+                          q_s=(ld, N * ld, 0), k_s=(ld, N * ld, 0), v_s=(ld, N * ld, 0), o_s=(d, N * d, 0), scale=scale))
+        tok = self._linear(o, T["o1"], Mp, residual=tok)
+        # x = x + attn2(norm2(x), context): the query side first — the last context-free step
+        n = be.layernorm(tok, *T["ln2"], 1e-5, dt)
+        q = self._linear(n, T["q2"], Mp, out_dtype=dt)
+        if share > 1:
+            tok, q, x = replicate(tok), q.repeat(share, 1), replicate(x)
+        o = torch.empty((M, d), dtype=dt, device=q.device)
+        kw = kv_all.shape[1]
+        k = kv_all[:, st._kv_off: st._kv_off + d]
+        v = kv_all[:, st._kv_off + d: st._kv_off + 2 * d]
+        # K/V rows are per prompt (every frame of a video reads the same 77 context rows: no x F repeat,
+        # unet_t2v.py:255) or, when a composition adds a per-frame token (histogram), per (prompt, frame)
+        kvs = (kw, F * Lctx * kw, Lctx * kw) if kv_per_frame else (kw, Lctx * kw, 0)
+        be.attention(Attn(q=q, k=k, v=v, out=o, heads=heads, nq=N, nk=Lctx, nbatch=B * F, inner=F,
+                          q_s=(d, F * N * d, N * d), k_s=kvs, v_s=kvs, o_s=(d, F * N * d, N * d), scale=scale))
+        tok = self._linear(o, T["o2"], M, residual=tok)
+        # x = x + ff(norm3(x)); the FF output is only consumed by proj_out -> emitted 16-bit (sum formed in fp32)
+        n = be.layernorm(tok, *T["ln3"], 1e-5, dt)
+        g = self._linear(n, T["ff1"], M, out_dtype=dt, epilogue=L.EPI_GEGLU)
+        t = self._linear(g, T["ff2"], M, residual=tok, out_dtype=dt)
         return self._linear(t, P["pout"], M, residual=x, colstats=True)
 
     def _temporal_tx(self, tt: _TemporalTransformerP, x, B, F, H, W):
@@ -656,9 +668,10 @@ class UNetSD_T2VBase(nn.Module):
 
         shared_groups = G > 1: the B units are G groups (group-major) with IDENTICAL stem inputs and row biases — the
         cond / uncond pair of classifier-free guidance, which differ only in their context.  Everything ahead of the
-        first cross-attention (stem conv, the first TemporalTransformer, the first ResBlock incl. its temporal convs:
-        ~7 % of a forward) is then evaluated ONCE on B/G units and its rows replicated; the reference runs it per
-        branch (diffusion_ddim.py:157-158)."""
+        first cross-attention (stem conv, the first TemporalTransformer, the first ResBlock incl. its temporal convs,
+        the first SpatialTransformer through its self-attention and cross-attention query: ~9 % of a forward) is then
+        evaluated ONCE on B/G units and its rows replicated; the reference runs it per branch
+        (diffusion_ddim.py:157-158)."""
         be = ops.backend()
         dt = self.compute_dtype
         P = self._packed
@@ -715,8 +728,14 @@ class UNetSD_T2VBase(nn.Module):
         rest = list(self.input_blocks)[1:]
         if G > 1:
             h, H, W = run(first[0], h, None, H, W, Bp)      # the first ResBlock: still no context involved
-            h = replicate(h)
-            for m in list(first)[1:]:
+            tail = list(first)[1:]
+            if tail and isinstance(tail[0], _SpatialTransformerP):
+                # ... nor is the first SpatialTransformer up to its cross-attention's key / value side
+                h = self._spatial_tx(tail[0], h, kv_all, B, F, H, W, Lctx, ctx_per_frame, share=G, replicate=replicate)
+                tail = tail[1:]
+            else:
+                h = replicate(h)
+            for m in tail:
                 h, H, W = run(m, h, None, H, W)
             xs.append((h, H, W))
             rest = rest[1:]
