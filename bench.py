@@ -38,6 +38,11 @@ Extra objects on the JSON line:
                  host cores on a bounded sample, scaled to a full step; rank 0 at N=1.
   vae / e2e    — AutoencoderKL decode frames/s; a whole video (50-step ddim_sample_loop + 16-frame decode).
   parity       — UNet rel-L2 vs the reference's fp32 forward for this dtype (from the committed GPU-test record).
+
+`model_tflops_per_s` / `frac_of_mfma_peak` count the REFERENCE's work per step (2 forwards x 8.665 TFLOP): the
+throughput in the reference's own units.  The kernels execute slightly less — the cond / uncond pair shares the layers
+ahead of the first cross-attention — which `roofline.tapgemm_tflop_per_step` (measured) shows; `roofline.achieved` is
+executed FLOP / measured kernel time.
 """
 from __future__ import annotations
 
@@ -327,7 +332,10 @@ def main():
                            "traffic": None, "launches_per_step": len(recs),
                            "avg_launch_us": round(1e3 * tot_ms / max(len(recs), 1), 2),
                            "avg_gflop_per_launch": round(tot_fl / max(len(recs), 1) / 1e9, 3),
-                           "tapgemm_ms_per_step": round(tot_ms, 3)}
+                           "tapgemm_ms_per_step": round(tot_ms, 3),
+                           # FLOP the kernel actually executed in one step (the CFG pair shares the layers ahead of the first
+                           # cross-attention, so this is a few % below the reference's 2 x forward count used in model_tflops_per_s)
+                           "tapgemm_tflop_per_step": round(tot_fl / 1e12, 3)}
         # HBM-side bytes per launch cannot be read from inside the process: they come from the committed
         # rocprofv3 PMC passes of this same command (tools/collect_evidence.sh -> profiles/)
         for tname in ("r02_tapgemm_traffic.json", "r01_tapgemm_traffic.json"):
