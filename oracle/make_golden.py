@@ -289,6 +289,37 @@ def make_trajectory(R, full):
         print("ddim_step_full", float(xt1.std()), float(x0.std()))
 
 
+def make_ddpm(R):
+    """The reference's ancestral sampler and closed-form q(.) helpers (diffusion_ddim.py:99-145) with the dummy model:
+    three p_sample steps (CFG, t = 999 / 500 / 0), a whole 1000-step p_sample_loop, one stochastic DDIM step (eta = 0.7),
+    both variance types.  RNG: torch.manual_seed on CPU — the sampler draws randn_like(xt) itself."""
+    g = torch.Generator("cpu").manual_seed(31)
+    noise = torch.randn(2, 4, 4, 8, 8, generator=g)
+    x0 = torch.randn(2, 4, 4, 8, 8, generator=g)
+    kw = [dict(y=torch.randn(2, 77, 16, generator=g)), dict(y=torch.randn(2, 77, 16, generator=g))]
+    out = dict(noise=noise, x0=x0, kw=kw, cfg=DDIM_T2V)
+    for vt in ("fixed_small", "fixed_large"):
+        diff = R["DIFFUSION"].build(dict(type="DiffusionDDIM", **dict(DDIM_T2V, var_type=vt)))
+        t = torch.tensor([999, 500])
+        torch.manual_seed(3)
+        steps = [diff.p_sample(noise.clone(), tt, dummy_model, kw, guide_scale=9.0)
+                 for tt in (torch.tensor([999, 500]), torch.tensor([1, 0]))]
+        pmv = diff.p_mean_variance(noise.clone(), t, dummy_model, kw, guide_scale=9.0)
+        torch.manual_seed(4)
+        loop = diff.p_sample_loop(noise.clone(), dummy_model, kw[0], guide_scale=None)
+        out[vt] = dict(steps=steps, pmv=pmv, loop=loop)
+    diff = R["DIFFUSION"].build(dict(type="DiffusionDDIM", **DDIM_T2V))
+    t = torch.tensor([981, 21])
+    torch.manual_seed(5)
+    out["ddim_eta"] = diff.ddim_sample(noise.clone(), t, dummy_model, kw, guide_scale=9.0, ddim_timesteps=50, eta=0.7)
+    out["q_mean_variance"] = diff.q_mean_variance(x0, t)
+    out["q_posterior"] = diff.q_posterior_mean_variance(x0, noise, t)
+    torch.manual_seed(6)
+    out["q_sample"] = diff.q_sample(x0, t)
+    torch.save(out, os.path.join(GOLD, "ddpm.pt"))
+    print("ddpm", {k: float(v["loop"].std()) for k, v in out.items() if isinstance(v, dict) and "loop" in v})
+
+
 def make_yardstick(R, full):
     """How far the reference's OWN mixed-precision arithmetic (amp.autocast, the mode its engines run:
     `use_fp16: True`, inference_text2video_entrance.py:197) lands from its fp32 forward on the fixtures' inputs —
@@ -355,6 +386,9 @@ def main():
         return
     if args.only == "yardstick":
         make_yardstick(R, args.full)
+        return
+    if args.only == "ddpm":
+        make_ddpm(R)
         return
     torch.manual_seed(0)
 

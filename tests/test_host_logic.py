@@ -110,6 +110,36 @@ def test_ddim_sampler_bit_exact_vs_reference_golden(emu_backend):
     assert torch.equal(xt1, g["step_xt1"]) and torch.equal(x0, g["step_x0"])
 
 
+def test_ancestral_sampler_and_q_helpers_bit_exact_vs_reference_golden(emu_backend):
+    """p_sample / p_sample_loop / p_mean_variance (both fixed variance types), the closed-form q(.) helpers, q_sample
+    with offset noise and a stochastic (eta = 0.7) DDIM step against the reference's outputs (oracle/make_golden.py
+    make_ddpm; the samplers draw their own noise, so the RNG stream must match draw for draw)."""
+    from oracle.make_golden import dummy_model
+    from vgen_amd.diffusion import DiffusionDDIM
+    g = gold("ddpm.pt")
+    same = lambda a, b: all(torch.equal(x, y) for x, y in zip(a, b)) and len(a) == len(b)
+    for vt in ("fixed_small", "fixed_large"):
+        d = DiffusionDDIM(**dict(g["cfg"], var_type=vt))
+        torch.manual_seed(3)
+        for tt, want in zip((torch.tensor([999, 500]), torch.tensor([1, 0])), g[vt]["steps"]):
+            assert same(d.p_sample(g["noise"].clone(), tt, dummy_model, g["kw"], guide_scale=9.0), want), vt
+        assert same(d.p_mean_variance(g["noise"].clone(), torch.tensor([999, 500]), dummy_model, g["kw"], guide_scale=9.0),
+                    g[vt]["pmv"]), vt
+        torch.manual_seed(4)
+        assert torch.equal(d.p_sample_loop(g["noise"].clone(), dummy_model, g["kw"][0], guide_scale=None), g[vt]["loop"])
+    d = DiffusionDDIM(**g["cfg"])
+    t = torch.tensor([981, 21])
+    torch.manual_seed(5)
+    assert same(d.ddim_sample(g["noise"].clone(), t, dummy_model, g["kw"], guide_scale=9.0, ddim_timesteps=50, eta=0.7),
+                g["ddim_eta"])
+    assert same(d.q_mean_variance(g["x0"], t), g["q_mean_variance"])
+    assert same(d.q_posterior_mean_variance(g["x0"], g["noise"], t), g["q_posterior"])
+    torch.manual_seed(6)
+    assert torch.equal(d.q_sample(g["x0"], t), g["q_sample"])
+    with pytest.raises(NotImplementedError):
+        d.p_sample(g["noise"], t, dummy_model, g["kw"], guide_scale=9.0, condition_fn=lambda *a, **k: 0)
+
+
 def test_ddim_call_pattern_and_rng_parity(emu_backend):
     from oracle.make_golden import dummy_model
     from vgen_amd.diffusion import DiffusionDDIM

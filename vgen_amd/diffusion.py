@@ -14,8 +14,10 @@ What is different underneath:
   * when the model exposes `forward_units` (vgen_amd.unet) the cond/uncond pair is evaluated as
     one batch (weights stream from HBM once per step), and when a UnitPartition is attached the
     units are spread over the ranks with a single all-gather per step (vgen_amd/parallel.py).
-Training-only members of the reference class (loss, VLB, PLMS, DDPM p_sample) are out of scope
-(SURVEY.md §8a / §2 row 1).
+The ancestral (DDPM) sampler p_sample / p_sample_loop (:116-144) and the closed-form q(.) helpers
+(:99-114) ride on the same fused x0 evaluation.  Training-only members of the reference class (loss, VLB)
+are out of scope; its plms_sample cannot run as shipped (`eps_cache` is read at
+:335 but is not a parameter of :290) and has no caller, so it is not restated.
 """
 from __future__ import annotations
 
@@ -99,6 +101,21 @@ class DiffusionDDIM(object):
         tab = self._table(x0.device)
         shape = (x0.size(0),) + (1,) * (x0.ndim - 1)
         return tab[_SQRT_AC][t].view(shape) * x0 + tab[_SQRT_1M][t].view(shape) * noise
+
+    def _g(self, table, t, x):
+        """table[t] as fp32 on x's device, broadcastable over x (the reference's `_i`, diffusion_ddim.py:10-16)."""
+        shape = (x.size(0),) + (1,) * (x.ndim - 1)
+        return table.to(x.device)[t].view(shape).to(x)
+
+    def q_mean_variance(self, x0, t):
+        """Distribution of q(x_t | x_0) (diffusion_ddim.py:99-105)."""
+        return (self._g(self.sqrt_alphas_cumprod, t, x0) * x0, self._g(1.0 - self.alphas_cumprod, t, x0),
+                self._g(self.log_one_minus_alphas_cumprod, t, x0))
+
+    def q_posterior_mean_variance(self, x0, xt, t):
+        """Distribution of q(x_{t-1} | x_t, x_0) (diffusion_ddim.py:107-114)."""
+        mu = self._g(self.posterior_mean_coef1, t, xt) * x0 + self._g(self.posterior_mean_coef2, t, xt) * xt
+        return mu, self._g(self.posterior_variance, t, xt), self._g(self.posterior_log_variance_clipped, t, xt)
 
     # -- model evaluation -------------------------------------------------------------------------
     def _eval_model(self, xt, t, model, model_kwargs, guide_scale):
@@ -191,16 +208,32 @@ class DiffusionDDIM(object):
     def p_mean_variance(self, xt, t, model, model_kwargs={}, clamp=None, percentile=None, guide_scale=None):
         """Returns (mu, var, log_var, x0) like the reference; x0 comes from the fused kernel."""
         _, x0 = self._fused(xt, t, model, model_kwargs, guide_scale, "x0", 0, 0.0, None, clamp, percentile)
-        shape = (xt.size(0),) + (1,) * (xt.ndim - 1)
-        g = lambda v: v.to(torch.float32).to(xt.device)[t].view(shape)
+        mu, var, log_var = self.q_posterior_mean_variance(x0, xt.float(), t)
         if self.var_type == "fixed_large":
-            var = g(torch.cat([self.posterior_variance[1:2], self.betas[1:]]))
+            var = self._g(torch.cat([self.posterior_variance[1:2], self.betas[1:]]), t, mu)
             log_var = torch.log(var)
-        else:
-            var = g(self.posterior_variance)
-            log_var = g(self.posterior_log_variance_clipped)
-        mu = g(self.posterior_mean_coef1) * x0 + g(self.posterior_mean_coef2) * xt
         return mu, var, log_var, x0
+
+    @torch.no_grad()
+    def p_sample(self, xt, t, model, model_kwargs={}, clamp=None, percentile=None, condition_fn=None, guide_scale=None):
+        """One ancestral step x_t -> x_{t-1} ~ N(mu, var) (diffusion_ddim.py:116-132); returns (x_{t-1}, x0)."""
+        if condition_fn is not None:
+            raise NotImplementedError("classifier guidance (condition_fn) is unused by the inference configs")
+        mu, var, log_var, x0 = self.p_mean_variance(xt, t, model, model_kwargs, clamp, percentile, guide_scale)
+        noise = torch.randn_like(xt)
+        mask = t.ne(0).float().view(-1, *((1,) * (xt.ndim - 1)))      # no noise when t == 0
+        return mu + mask * torch.exp(0.5 * log_var) * noise, x0
+
+    @torch.no_grad()
+    def p_sample_loop(self, noise, model, model_kwargs={}, clamp=None, percentile=None, condition_fn=None,
+                      guide_scale=None):
+        """All num_timesteps ancestral steps (diffusion_ddim.py:134-145)."""
+        b = noise.size(0)
+        xt = noise
+        for step in torch.arange(self.num_timesteps).flip(0):
+            t = torch.full((b,), int(step), dtype=torch.long, device=xt.device)
+            xt, _ = self.p_sample(xt, t, model, model_kwargs, clamp, percentile, condition_fn, guide_scale)
+        return xt
 
     @torch.no_grad()
     def ddim_sample(self, xt, t, model, model_kwargs={}, clamp=None, percentile=None, condition_fn=None,
