@@ -320,6 +320,56 @@ def make_ddpm(R):
     print("ddpm", {k: float(v["loop"].std()) for k, v in out.items() if isinstance(v, dict) and "loop" in v})
 
 
+def make_blocks(R):
+    """Per-block goldens ("no per-block (ResBlock / ST / TT) GPU golden"): forward hooks on EVERY
+    ResBlock (incl. its TemporalConvBlock_v2), SpatialTransformer, TemporalTransformer, Downsample and Upsample of the
+    reference's tiny UNetSD_T2VBase record each block's input and output.  The fixture stores every output once (as
+    [B*F, C, H, W] fp32) plus, per block, where its input came from: the previous block's output, or — decoder
+    ResBlocks — that concatenated with an earlier output (unet_t2v.py:262-264).  A test can then feed each block of
+    the HIP model the REFERENCE's input and compare with the reference's output: errors do not accumulate along the
+    depth, a wrong block is named."""
+    g = torch.load(os.path.join(GOLD, "unet_tiny.pt"), weights_only=False)
+    m = R["MODEL"].build(dict(type="UNetSD_T2VBase", **g["cfg"])).eval()
+    m.load_state_dict(torch_ref.synth_state_dict(g["shapes"], seed=g["seed"]), strict=True)
+    B, F, H, W = 2, 4, 8, 8
+    gen = torch.Generator("cpu").manual_seed(77)
+    x = torch.randn(B, 4, F, H, W, generator=gen)
+    y = torch.randn(B, 77, 1024, generator=gen)
+    t = torch.tensor([741, 61])
+    kinds = ("ResBlock", "SpatialTransformer", "TemporalTransformer", "Downsample", "Upsample")
+    canon = lambda v: v.permute(0, 2, 1, 3, 4).reshape(-1, v.shape[1], *v.shape[3:]) if v.dim() == 5 else v
+    recs, outs = [], []
+
+    def hook(name):
+        def fn(mod, args, out):
+            xin, o = canon(args[0]).float(), canon(out).float()
+            src = None
+            for j in range(len(outs) - 1, -1, -1):                      # whole input = an earlier output
+                if outs[j].shape == xin.shape and torch.equal(outs[j], xin):
+                    src = (j,)
+                    break
+            if src is None and outs:                                    # cat(previous output, an earlier output)
+                c1 = outs[-1].shape[1]
+                if xin.shape[1] > c1 and outs[-1].shape[2:] == xin.shape[2:] and torch.equal(outs[-1], xin[:, :c1]):
+                    for j in range(len(outs) - 1, -1, -1):
+                        if outs[j].shape == xin[:, c1:].shape and torch.equal(outs[j], xin[:, c1:]):
+                            src = (len(outs) - 1, j)
+                            break
+            recs.append(dict(name=name, kind=type(mod).__name__, src=src, x=None if src else xin.clone(),
+                             H=xin.shape[2], W=xin.shape[3]))
+            outs.append(o.clone())
+        return fn
+
+    hs = [mod.register_forward_hook(hook(n)) for n, mod in m.named_modules() if type(mod).__name__ in kinds]
+    with torch.no_grad():
+        out = m(x, t, y=y)
+    for h in hs:
+        h.remove()
+    assert sum(r["x"] is not None for r in recs) == 1, [r["name"] for r in recs if r["x"] is not None]
+    torch.save(dict(x=x, y=y, t=t, out=out, recs=recs, outs=outs, B=B, F=F), os.path.join(GOLD, "unet_blocks_tiny.pt"))
+    print("blocks", len(recs), [(r["name"], r["kind"], r["src"]) for r in recs][:8], "...")
+
+
 def make_yardstick(R, full):
     """How far the reference's OWN mixed-precision arithmetic (amp.autocast, the mode its engines run:
     `use_fp16: True`, inference_text2video_entrance.py:197) lands from its fp32 forward on the fixtures' inputs —
@@ -389,6 +439,9 @@ def main():
         return
     if args.only == "ddpm":
         make_ddpm(R)
+        return
+    if args.only == "blocks":
+        make_blocks(R)
         return
     torch.manual_seed(0)
 

@@ -40,6 +40,17 @@ def test_unet_host_logic_vs_reference_golden(emu_backend, dtname, tol):
     assert rel_l2(out, g["out"]) < tol
 
 
+def test_every_block_alone_vs_reference_golden(emu_backend):
+    """Host logic of each block (operand packing, row / stride bookkeeping, skip-concat split, temporal layout) on the
+    reference's own per-block inputs — see tests/block_cases.py; the kernels proper are the GPU twin of this test."""
+    from block_cases import run_blocks
+    res = run_blocks("fp16", "cpu")
+    assert len(res) == 36 and {k for k, _ in res.values()} == {"ResBlock", "SpatialTransformer", "TemporalTransformer",
+                                                               "Downsample", "Upsample"}
+    bad = {n: v for n, v in res.items() if not v[1] < 2e-3}
+    assert not bad, bad
+
+
 def test_unet_other_shapes_vs_oracle(emu_backend):
     m, g, sd = _unet("fp16")
     gen = torch.Generator().manual_seed(9)
