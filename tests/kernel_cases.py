@@ -318,6 +318,8 @@ def tapgemm_cases(dt):
                                     Wo=4, stride=2, pad_t=1, pad_l=1, ups=0)
     c["conv_ups"] = make_tapgemm(dt, 2 * 10 * 12, 192, 64, mode=L.TAP_CONV3X3, nimg=2, Hi=5, Wi=6, Ho=10,
                                  Wo=12, stride=1, pad_t=1, pad_l=1, ups=1)
+    c["conv_ups_crop"] = make_tapgemm(dt, 2 * 10 * 10, 64, 64, mode=L.TAP_CONV3X3, nimg=2, Hi=6, Wi=5, Ho=10,
+                                      Wo=10, stride=1, pad_t=1, pad_l=1, ups=1, crop_t=1)     # SR600 Upsample: 2x, crop 1 row each side
     c["conv_vae_down"] = make_tapgemm(dt, 2 * 4 * 3, 64, 64, mode=L.TAP_CONV3X3, nimg=2, Hi=8, Wi=6, Ho=4,
                                       Wo=3, stride=2, pad_t=0, pad_l=0, ups=0)
     c["conv_skipseg"] = make_tapgemm(dt, 2 * 6 * 6, 128, 128, mode=L.TAP_CONV3X3, nimg=2, Hi=6, Wi=6, Ho=6,

@@ -49,6 +49,41 @@ def test_tapgemm(hip_backend, dtname, name):
         assert cs["finite"] and cs["rel_l2"] <= 2e-5, cs
 
 
+@pytest.mark.parametrize("dtname", ["bf16", "fp16"])
+def test_kernels_vs_plain_torch_operators(hip_backend, dtname):
+    """The HIP kernels against torch's own fp32 operators on NCHW tensors (tests/torch_ops_ref.py: F.conv2d / conv1d /
+    linear / group_norm / layer_norm / scaled_dot_product_attention), every tap-GEMM and attention case plus GroupNorm
+    and LayerNorm — no layout convention of the ABI is shared with this reference."""
+    import torch_ops_ref as tr
+    dt = kc.DTS[dtname]
+    tol16 = kc.TOL16[dtname]
+    for name, spec in kc.tapgemm_cases(dt).items():
+        out = hip_backend.tapgemm(kc._clone_spec(spec, DEV)).float().cpu()
+        err = kc.stats(out, tr.ref_tapgemm(spec))["rel_l2"]
+        assert err <= (tol16 if spec.out_dtype != torch.float32 else kc.TOL32), (name, err)
+    g = torch.Generator().manual_seed(3)
+    for nb, S, C1, C2, silu in [(2, 1792, 320, 0, True), (3, 448, 640, 640, False), (16, 28, 1280, 0, True)]:
+        x1 = torch.randn(nb * S, C1, generator=g) * 1.7 + 0.6
+        x2 = torch.randn(nb * S, C2, generator=g) if C2 else None
+        ga, be_ = 1 + 0.2 * torch.randn(C1 + C2, generator=g), 0.3 * torch.randn(C1 + C2, generator=g)
+        y, _ = hip_backend.groupnorm(x1.to(DEV), None if x2 is None else x2.to(DEV), nb, S, 32, 1e-5, ga.to(DEV),
+                                     be_.to(DEV), silu, False, dt)
+        err = kc.stats(y, tr.ref_groupnorm(x1, x2, nb, S, 32, 1e-5, ga, be_, silu))["rel_l2"]
+        assert err <= tol16, ("groupnorm", nb, S, err)
+    x = torch.randn(3000, 320, generator=g) * 2 + 0.5
+    ga, be_ = 1 + 0.2 * torch.randn(320, generator=g), 0.3 * torch.randn(320, generator=g)
+    err = kc.stats(hip_backend.layernorm(x.to(DEV), ga.to(DEV), be_.to(DEV), 1e-5, dt), tr.ref_layernorm(x, ga, be_, 1e-5))["rel_l2"]
+    assert err <= tol16, ("layernorm", err)
+    for name, spec in kc.attn_cases(dt).items():
+        dspec = kc._clone_spec(spec, DEV)
+        hip_backend.attention(dspec)
+        cspec = kc._clone_spec(spec, "cpu")
+        cspec.out = dspec.out.cpu()
+        ref, got = tr.ref_attention(cspec)
+        err = kc.stats(got, ref)["rel_l2"]
+        assert err <= 3 * tol16, (name, err)     # P is rounded to 16 bit before the PV product
+
+
 _AT = sorted(kc.attn_cases(torch.bfloat16))
 
 

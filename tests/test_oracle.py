@@ -114,3 +114,38 @@ def test_oracle_vae_and_sampler_vs_live_reference():
     a = diff.ddim_sample_loop(noise.clone(), dummy_model, kw, guide_scale=7.5, ddim_timesteps=25, eta=0.0)
     b = torch_ref.ddim_sample_loop(diff.betas, noise.clone(), dummy_model, kw, 7.5, 25, "v", 0.0)
     assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the ABI emulator (the reference of the kernel-level GPU tests) against torch's own operators
+def test_abi_emulator_vs_plain_torch_operators():
+    """oracle/abi_emulator.py restates every kernel on the ABI's row layouts; here each family is recomputed with
+    F.conv2d / F.conv1d / F.linear / F.group_norm / F.layer_norm / F.scaled_dot_product_attention on NCHW tensors
+    (tests/torch_ops_ref.py) for every kernel-test case: tap order, asymmetric / stride-2 padding, the folded nearest
+    upsample + crop, the (3,1,1) temporal taps, packed GEGLU columns, the attention stride regimes."""
+    import kernel_cases as kc
+    import torch_ops_ref as tr
+    from oracle.abi_emulator import EmuBackend
+    emu = EmuBackend()
+    dt = torch.float16
+    for name, spec in kc.tapgemm_cases(dt).items():
+        ref = tr.ref_tapgemm(spec)
+        out = emu.tapgemm(kc._clone_spec(spec, "cpu")).float()
+        tol = 1e-3 if spec.out_dtype != torch.float32 else 2e-5       # 16-bit outputs: one rounding of the result
+        assert rel_l2(out, ref) < tol, (name, rel_l2(out, ref))
+    g = torch.Generator().manual_seed(3)
+    for nb, S, C1, C2, silu in [(2, 96, 64, 0, True), (3, 40, 64, 32, False), (1, 128, 320, 0, True)]:
+        x1 = torch.randn(nb * S, C1, generator=g) * 1.7 + 0.6
+        x2 = torch.randn(nb * S, C2, generator=g) if C2 else None
+        ga, be_ = 1 + 0.2 * torch.randn(C1 + C2, generator=g), 0.3 * torch.randn(C1 + C2, generator=g)
+        y, _ = emu.groupnorm(x1, x2, nb, S, 32, 1e-5, ga, be_, silu, False, torch.float32)
+        assert rel_l2(y, tr.ref_groupnorm(x1, x2, nb, S, 32, 1e-5, ga, be_, silu)) < 2e-6
+    x = torch.randn(70, 320, generator=g) * 2 + 0.5
+    ga, be_ = 1 + 0.2 * torch.randn(320, generator=g), 0.3 * torch.randn(320, generator=g)
+    assert rel_l2(emu.layernorm(x, ga, be_, 1e-5, torch.float32), tr.ref_layernorm(x, ga, be_, 1e-5)) < 2e-6
+    for name, spec in kc.attn_cases(dt).items():
+        spec = kc._clone_spec(spec, "cpu")
+        spec.out = spec.out.float()
+        emu.attention(spec)
+        ref, got = tr.ref_attention(spec)
+        assert rel_l2(got, ref) < 2e-6, (name, rel_l2(got, ref))
