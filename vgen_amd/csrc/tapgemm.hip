@@ -135,6 +135,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   }
   const int64_t m0 = (tile / tiles_n) * BM;
   const int n0 = (int)(tile % tiles_n) * BN;
+  // `ablate` bit 3 (tuning switch, see below): every block stages tile (0, 0)'s operands — all DMA traffic hits the L2,
+  // the K loop is otherwise unchanged: separates fabric / L2-miss bandwidth from what the CU itself can sustain
+  const int64_t lm0 = (ablate & 8) ? 0 : m0;
+  const int ln0 = (ablate & 8) ? 0 : n0;
 
   const uint16_t* __restrict__ A = (const uint16_t*)p.A;
   const uint16_t* __restrict__ A2 = (const uint16_t*)p.A2;
@@ -150,7 +154,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
 #pragma unroll
   for (int i = 0; i < RA; ++i) {
     // M < 2^31 is enforced by the host wrapper: 32-bit index math (64-bit divides cost ~1 us/block)
-    const unsigned m = (unsigned)m0 + ld_r + RPP * i;
+    const unsigned m = (unsigned)lm0 + ld_r + RPP * i;
     const bool ok = m < (unsigned)p.M;
     if (ok) mvalid |= 1u << i;
     if (p.mode == VGEN_TAP_CONV3X3) {
@@ -183,7 +187,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   const int kt_end = (int)(((int64_t)KT * (split + 1)) / splitk);
   // `ablate` (tuning switch VGEN_TAPGEMM_ABLATE, 0 in production): bit 0 skips the K loop, bit 1 the epilogue's
   // stores — the phase decomposition of a launch (profiles/r02_tapgemm_ablation.json); bit 2 takes the 8-byte
-  // store path for 16-bit outputs (A/B of the paired 16-byte stores)
+  // store path for 16-bit outputs (A/B of the paired 16-byte stores); bit 3 see lm0 above
+  // (profiles/r02_tapgemm_l2_ablation.json: the K loop is not fabric-bound)
   const int nk = (ablate & 1) ? 0 : kt_end - kt_begin;
 
   // ---- incremental per-lane DMA source pointers ---------------------------------------------
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
         const bool ok = (mvalid >> i) & 1u;
-        pc[i] = (ok ? (const char*)(A2 + (int64_t)((unsigned)m0 + ld_r + RPP * i) * p.lda2 + (kt - T1) * BK) : zline) +
+        pc[i] = (ok ? (const char*)(A2 + (int64_t)((unsigned)lm0 + ld_r + RPP * i) * p.lda2 + (kt - T1) * BK) : zline) +
                 src_cb;
       }
     }
@@ -243,7 +248,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   gather_a(kt_begin);
 #pragma unroll
   for (int i = 0; i < NP - RA; ++i) {
-    const int n = n0 + ld_r + RPP * i;
+    const int n = ln0 + ld_r + RPP * i;
     const bool ok = n < p.N;
     pc[RA + i] = (ok ? (const char*)(W + (int64_t)n * ldw + (int64_t)kt_begin * BK) : zline) + src_cb;
   }
