@@ -110,7 +110,7 @@ def randomize_(module, seed):
                 p.copy_(0.1 * torch.randn(p.shape, generator=g, device=p.device))
 
 
-def build_model(name, dev, dtype):
+def build_model(name, dev, dtype, precision="fast"):
     import importlib
     import types
     c = CONFIGS[name]
@@ -120,7 +120,7 @@ def build_model(name, dev, dtype):
     if "comps" in c:
         kw["config"] = types.SimpleNamespace(video_compositions=c["comps"], resolution=[c["latent"][3] * 8, c["latent"][2] * 8])
     with torch.device(dev):
-        model = cls(**kw, compute_dtype=dtype)
+        model = cls(**kw, compute_dtype=dtype, precision=precision)
     model.eval()
     randomize_(model, 0)
     model.pack()
@@ -154,6 +154,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16"])
     ap.add_argument("--config", default="t2v", choices=sorted(CONFIGS))
+    ap.add_argument("--precision", default="fast", choices=["fast", "high"],
+                    help="high: every packed weight carries its 16-bit rounding residual as a second operand (UNet rel-L2 "
+                         "<= 1e-3 from the reference's fp32 forward; ~2x the tap-GEMM time) — not the headline mode")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true")
@@ -195,7 +198,7 @@ def main():
     cfg = CONFIGS[args.config]
     C, F, H, W = cfg["latent"]
     G = cfg["G"]
-    model = build_model(args.config, dev, args.dtype)
+    model = build_model(args.config, dev, args.dtype, args.precision)
     if args.config == "t2v":                          # fp32 masters are not needed for sampling (the variants'
         for p in model.parameters():                  # condition stems run on theirs)
             p.data = torch.empty(0, device=dev)
@@ -267,7 +270,8 @@ def main():
                    "parallelism": "single GPU" if world == 1 else
                    f"unit partition over {world} ranks, 1 all-gather/step ({args.backend}{', all ranks on one device: functional test' if one_dev else ''})",
                    "hipgraph": bool(sess is not None and sess.use_graph and sess._graphs) and
-                   ("whole step" if part is None else "local units' forward")},
+                   ("whole step" if part is None else "local units' forward"),
+                   "precision": args.precision},
         "finite": finite, "latent_absmax_after_timed_steps": xt_absmax,
         "model_tflops_per_s": round(G * cfg["tflop"] * steps_per_s, 2),
         "frac_of_mfma_peak": round(G * cfg["tflop"] * steps_per_s / world / PEAK_TFLOPS, 4),
@@ -275,7 +279,7 @@ def main():
     ppath = os.path.join(ROOT, "profiles", "r02_parity.json")
     if os.path.exists(ppath) and args.config == "t2v":
         pj = json.load(open(ppath))
-        key = f"unet_t2v_full/{args.dtype}"
+        key = f"unet_t2v_full/{args.dtype}" + ("/high" if args.precision == "high" else "")
         if key in pj:
             res["parity"] = {"dtype": args.dtype, "unet_rel_l2": pj[key],
                              "reference_own_autocast_rel_l2": pj.get(f"reference_autocast/{args.dtype}"),

@@ -91,6 +91,8 @@ class EmuBackend:
         assert dt in (torch.bfloat16, torch.float16) and g.W.dtype == dt
         K = g.taps * g.C1 + g.C2
         W = g.W[: g.N, :K].float()
+        if getattr(g.W, "vgen_lo", None) is not None:     # high-precision mode: the launches compute A (W_hi + W_lo)^T
+            W = W + g.W.vgen_lo[: g.N, :K].float()
         acc = torch.zeros((g.M, g.N), dtype=torch.float32)
         for tap, r in enumerate(self._src_rows(g)):
             a = g.A[:, : g.C1][r.clamp(min=0)].float()

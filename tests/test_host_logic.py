@@ -51,6 +51,47 @@ def test_every_block_alone_vs_reference_golden(emu_backend):
     assert not bad, bad
 
 
+def test_high_precision_mode_splits_every_packed_weight(emu_backend):
+    """precision="high": the packers attach the rounding residual to every 16-bit weight operand (W_hi + W_lo == the
+    fp32 weight to ~2^-21), linear launches take it as a second K segment and tap gathers as a second launch — checked
+    on the launch stream; the tiny UNet moves from 1.5e-3 to 1.1e-3 of the reference's fp32 forward."""
+    from vgen_amd import ops
+    m, g, sd = _unet("fp16")
+    from vgen_amd.unet import UNetSD_T2VBase
+    mh = UNetSD_T2VBase(**g["cfg"], compute_dtype="fp16", precision="high").eval()
+    mh.load_state_dict(sd, strict=True)
+    P = mh.pack()
+    name = next(n for n, mod in mh.named_modules() if type(mod).__name__ == "_ResBlockP" and isinstance(mod.skip_connection, torch.nn.Conv2d))
+    for w in (P[name]["conv1"][0], P[name]["conv2"][0], P[name]["tconv1"][0], P["kv_all"],
+              P[next(n for n, mod in mh.named_modules() if type(mod).__name__ == "_SpatialTransformerP")]["tb"]["ff1"][0]):
+        assert w.vgen_lo.shape == w.shape and w.vgen_hilo.shape == (w.shape[0], 2 * w.shape[1])
+        assert getattr(w.vgen_plain, "vgen_lo", None) is None
+    rb = mh.get_submodule(name)
+    full = torch.cat([rb.out_layers[3].weight.detach().permute(0, 2, 3, 1).reshape(rb.cout, -1), rb.skip_connection.weight.detach().reshape(rb.cout, -1)], 1)
+    w = P[name]["conv2"][0]
+    assert float(((w.float() + w.vgen_lo.float()) - full).abs().max() / full.abs().max()) < 2e-6
+    e_fast = rel_l2(m(g["x"], g["t"], y=g["y"]), g["out"])
+    e_high = rel_l2(mh(g["x"], g["t"], y=g["y"]), g["out"])
+    assert e_high < 0.8 * e_fast and e_high < 1.2e-3, (e_fast, e_high)
+    # the decomposition itself, launch by launch, on a recording backend
+    seen = []
+    be = ops.backend()
+    orig = be.tapgemm
+    be.tapgemm = lambda spec: (seen.append((spec.mode, spec.C2, getattr(spec.W, "vgen_lo", None) is not None)), orig(spec))[1]
+    try:
+        x = torch.randn(64, 128).half()
+        w = ops.split_weight(torch.randn(64, 128), torch.float16)
+        ops._tapgemm_weight_split(be, ops.TapGemm(A=x, W=w, M=64, N=64, C1=128))
+        assert seen == [(0, 128, False)]                                      # one launch, K doubled
+        seen.clear()
+        wt = ops.split_weight(torch.randn(64, 3 * 64), torch.float16)
+        xt = torch.randn(2 * 4 * 8, 64).half()
+        ops._tapgemm_weight_split(be, ops.TapGemm(A=xt, W=wt, M=64, N=64, C1=64, mode=2, taps=3, F=4, S=8, bias=torch.randn(64)))
+        assert [s[0] for s in seen] == [2, 2] and not any(s[2] for s in seen)   # two gathers: W_hi, then W_lo on top
+    finally:
+        del be.tapgemm
+
+
 def test_unet_other_shapes_vs_oracle(emu_backend):
     m, g, sd = _unet("fp16")
     gen = torch.Generator().manual_seed(9)

@@ -113,6 +113,35 @@ def _mat(t: torch.Tensor, name: str):
     return t
 
 
+def split_weight(p32: torch.Tensor, dt) -> torch.Tensor:
+    """fp32 packed weight [N, K] -> its 16-bit rounding W_hi, carrying the rounding residual as a second 16-bit operand:
+    `vgen_lo` = round16(W - W_hi) (W_hi + W_lo reproduces W to ~2^-22 relative in fp16), `vgen_hilo` = [W_hi | W_lo] for
+    launches that can take the correction as a second K segment, `vgen_plain` = W_hi without the companions.  The
+    high-precision mode of the models (precision="high"): packed weights are the largest single rounding in the UNet
+     and the only one that can be removed without touching an activation."""
+    hi = p32.to(dt).contiguous()
+    lo = (p32.float() - hi.float()).to(dt).contiguous()
+    hi.vgen_lo = lo
+    hi.vgen_hilo = torch.cat([hi, lo], 1).contiguous()
+    hi.vgen_plain = hi.detach()
+    return hi
+
+
+def _tapgemm_weight_split(be, g: TapGemm):
+    """out = epi(A . (W_hi + W_lo)^T): a linear launch takes W_lo as its second K segment over the same rows (one
+    launch, K doubled, every epilogue as usual); gathers (3x3 / temporal taps) and launches that already use the second
+    segment run twice — W_hi with bias / row bias / residual into an fp32 temporary, then W_lo on top of it with the
+    launch's own output type, column statistics and workspace."""
+    import dataclasses
+    W = g.W
+    if g.mode == _lib.TAP_LINEAR and g.C2 == 0 and g.A2 is None:
+        return be.tapgemm(dataclasses.replace(g, W=W.vgen_hilo, A2=g.A, C2=g.C1))
+    assert g.epilogue == _lib.EPI_NONE, "GEGLU launches are linear"
+    lo = W.vgen_lo
+    t = be.tapgemm(dataclasses.replace(g, W=W.vgen_plain, out=None, out_dtype=torch.float32, colstats=False))
+    return be.tapgemm(dataclasses.replace(g, W=lo, bias=None, rowbias=None, rows_per_rb=0, residual=t))
+
+
 class HipBackend:
     name = "hip"
 
@@ -185,6 +214,8 @@ class HipBackend:
 
     # -- tap GEMM --------------------------------------------------------------------------
     def tapgemm(self, g: TapGemm):
+        if getattr(g.W, "vgen_lo", None) is not None:
+            return _tapgemm_weight_split(self, g)
         A = _mat(g.A, "A")
         W = _mat(g.W, "W")
         n_out = g.N // 2 if g.epilogue == _lib.EPI_GEGLU else g.N

@@ -145,18 +145,35 @@ class _UpP(nn.Module):
 # ------------------------------------------------------------------------------------------
 # weight packing helpers (fp32 parameters -> 16-bit tap-GEMM operands)
 # ------------------------------------------------------------------------------------------
-def pack_conv3x3(w: torch.Tensor, dt) -> torch.Tensor:
-    """[Cout, Cin, 3, 3] -> [Cout, 9*Cin], column (ky*3+kx)*Cin + c."""
-    return w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(dt).contiguous()
+_SPLIT_WEIGHTS = False     # set by pack() of a model built with precision="high" (ops.split_weight)
+
+
+def _w16(p32: torch.Tensor, dt) -> torch.Tensor:
+    """packed fp32 [N, K] -> the 16-bit tap-GEMM operand (+ its rounding residual in high-precision mode)"""
+    if _SPLIT_WEIGHTS:
+        return ops.split_weight(p32.float(), dt)
+    return p32.to(dt).contiguous()
+
+
+def _w16_cat(parts, dt) -> torch.Tensor:
+    """column-concatenated operand (ResBlock out-conv + its 1x1 skip conv as a second K segment)"""
+    return _w16(torch.cat([p.float() for p in parts], 1), dt)
+
+
+def pack_conv3x3(w: torch.Tensor, dt=None) -> torch.Tensor:
+    """[Cout, Cin, 3, 3] -> [Cout, 9*Cin], column (ky*3+kx)*Cin + c (fp32 when dt is None)."""
+    p = w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1)
+    return p if dt is None else _w16(p, dt)
 
 
 def pack_temporal(w: torch.Tensor, dt) -> torch.Tensor:
     """[Cout, Cin, 3, 1, 1] -> [Cout, 3*Cin], column kt*Cin + c."""
-    return w.detach()[:, :, :, 0, 0].permute(0, 2, 1).reshape(w.shape[0], -1).to(dt).contiguous()
+    return _w16(w.detach()[:, :, :, 0, 0].permute(0, 2, 1).reshape(w.shape[0], -1), dt)
 
 
-def pack_linear(w: torch.Tensor, dt) -> torch.Tensor:
-    return w.detach().reshape(w.shape[0], -1).to(dt).contiguous()
+def pack_linear(w: torch.Tensor, dt=None) -> torch.Tensor:
+    p = w.detach().reshape(w.shape[0], -1)
+    return p if dt is None else _w16(p, dt)
 
 
 def pack_geglu(w: torch.Tensor, b: torch.Tensor, dt):
@@ -165,7 +182,7 @@ def pack_geglu(w: torch.Tensor, b: torch.Tensor, dt):
     assert inner % 16 == 0
     idx = torch.arange(inner, device=w.device).view(-1, 16)
     perm = torch.cat([idx, idx + inner], dim=1).reshape(-1)
-    return w.detach()[perm].to(dt).contiguous(), b.detach()[perm].float().contiguous()
+    return _w16(w.detach()[perm], dt), b.detach()[perm].float().contiguous()
 
 
 def pack_small_conv3x3(w: torch.Tensor, kpad: int, dt, split: bool = False) -> torch.Tensor:
@@ -203,7 +220,7 @@ class UNetSD_T2VBase(nn.Module):
                  temporal_attention=True, use_checkpoint=False, use_image_dataset=False,
                  use_sim_mask=False, training=True, inpainting=True, use_fps_condition=False,
                  p_all_zero=0.1, p_all_keep=0.1, zero_y=None, adapter_transformer_layers=1,
-                 compute_dtype=None, **kwargs):
+                 compute_dtype=None, precision=None, **kwargs):
         super().__init__()
         if head_dim != HEAD_DIM:
             raise NotImplementedError("vgen_amd attention kernels are built for head_dim 64")
@@ -220,6 +237,11 @@ class UNetSD_T2VBase(nn.Module):
         self.attn_scales = list(attn_scales)
         self.use_fps_condition = use_fps_condition
         self.compute_dtype = ops.sixteen(compute_dtype)
+        # "fast": one 16-bit operand pair per GEMM (the reference's autocast arithmetic; 1.33e-3 from its fp32 forward);
+        # "high": every packed weight also carries its 16-bit rounding residual and the GEMMs add A . W_lo — removes the
+        # largest rounding category at ~2x the tap-GEMM time; set before the first forward / pack()
+        self.precision = precision or "fast"
+        assert self.precision in ("fast", "high")
 
         enc_dims = [dim * u for u in [1] + list(dim_mult)]
         dec_dims = [dim * u for u in [dim_mult[-1]] + list(dim_mult)[::-1]]
@@ -310,6 +332,14 @@ class UNetSD_T2VBase(nn.Module):
     @torch.no_grad()
     def pack(self, device=None):
         """Build the 16-bit tap-GEMM operands (once per weight load)."""
+        global _SPLIT_WEIGHTS
+        _SPLIT_WEIGHTS = self.precision == "high"
+        try:
+            return self._pack(device)
+        finally:
+            _SPLIT_WEIGHTS = False
+
+    def _pack(self, device=None):
         dt = self.compute_dtype
         P = {}
         # time (and fps) embedding MLPs and all 22 ResBlock emb_layers ([sum(Cout), embed_dim], one matrix) stay
@@ -354,11 +384,12 @@ class UNetSD_T2VBase(nn.Module):
             d["gn1"] = (_f32(rb.in_layers[0].weight), _f32(rb.in_layers[0].bias))
             d["conv1"] = (pack_conv3x3(rb.in_layers[2].weight, dt), _f32(rb.in_layers[2].bias))
             d["gn2"] = (_f32(rb.out_layers[0].weight), _f32(rb.out_layers[0].bias))
-            w2 = pack_conv3x3(rb.out_layers[3].weight, dt)
             b2 = _f32(rb.out_layers[3].bias)
             if isinstance(rb.skip_connection, nn.Conv2d):
-                w2 = torch.cat([w2, pack_linear(rb.skip_connection.weight, dt)], 1).contiguous()
+                w2 = _w16_cat([pack_conv3x3(rb.out_layers[3].weight), pack_linear(rb.skip_connection.weight)], dt)
                 b2 = (b2 + _f32(rb.skip_connection.bias)).contiguous()
+            else:
+                w2 = pack_conv3x3(rb.out_layers[3].weight, dt)
             d["conv2"] = (w2, b2)
             tc = rb.temopral_conv
             for i in (1, 2, 3, 4):
@@ -792,7 +823,7 @@ class UNetSD_SR600(UNetSD_T2VBase):
                          temporal_attn_times=temporal_attn_times, temporal_attention=temporal_attention,
                          use_checkpoint=use_checkpoint, use_image_dataset=use_image_dataset,
                          use_sim_mask=use_sim_mask, inpainting=inpainting, use_fps_condition=False,
-                         compute_dtype=compute_dtype)
+                         compute_dtype=compute_dtype, precision=kwargs.get("precision"))
 
     @torch.no_grad()
     def forward(self, x, t, y, x_lr=None, fps=None, video_mask=None, focus_present_mask=None,
