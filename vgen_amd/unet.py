@@ -148,6 +148,22 @@ class _UpP(nn.Module):
 _SPLIT_WEIGHTS = False     # set by pack() of a model built with precision="high" (ops.split_weight)
 
 
+class split_weights:
+    """`with split_weights(model.precision == "high"):` around a pack(): the packers below then keep every operand's
+    rounding residual (high-precision mode of the UNets and the VAE)."""
+
+    def __init__(self, on):
+        self.on = bool(on)
+
+    def __enter__(self):
+        global _SPLIT_WEIGHTS
+        self.prev, _SPLIT_WEIGHTS = _SPLIT_WEIGHTS, self.on
+
+    def __exit__(self, *exc):
+        global _SPLIT_WEIGHTS
+        _SPLIT_WEIGHTS = self.prev
+
+
 def _w16(p32: torch.Tensor, dt) -> torch.Tensor:
     """packed fp32 [N, K] -> the 16-bit tap-GEMM operand (+ its rounding residual in high-precision mode)"""
     if _SPLIT_WEIGHTS:
@@ -332,12 +348,8 @@ class UNetSD_T2VBase(nn.Module):
     @torch.no_grad()
     def pack(self, device=None):
         """Build the 16-bit tap-GEMM operands (once per weight load)."""
-        global _SPLIT_WEIGHTS
-        _SPLIT_WEIGHTS = self.precision == "high"
-        try:
+        with split_weights(self.precision == "high"):
             return self._pack(device)
-        finally:
-            _SPLIT_WEIGHTS = False
 
     def _pack(self, device=None):
         dt = self.compute_dtype

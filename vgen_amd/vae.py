@@ -23,7 +23,7 @@ import torch.nn as nn
 from . import lib as L
 from . import ops
 from .ops import TapGemm
-from .unet import _f32, pack_conv3x3, pack_linear, pack_small_conv3x3
+from .unet import _f32, _w16_cat, pack_conv3x3, pack_linear, pack_small_conv3x3, split_weights
 
 
 def _norm(c):
@@ -157,7 +157,7 @@ class DiagonalGaussianDistribution(object):
 class AutoencoderKL(nn.Module):
     def __init__(self, ddconfig, embed_dim, pretrained=None, ignore_keys=[], image_key="image",
                  colorize_nlabels=None, monitor=None, ema_decay=None, learn_logvar=False,
-                 use_vid_decoder=False, compute_dtype=None, **kwargs):
+                 use_vid_decoder=False, compute_dtype=None, precision=None, **kwargs):
         super().__init__()
         self.learn_logvar = learn_logvar
         self.image_key = image_key
@@ -173,6 +173,8 @@ class AutoencoderKL(nn.Module):
         self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
         self.embed_dim = embed_dim
         self.compute_dtype = ops.sixteen(compute_dtype)
+        self.precision = precision or "fast"      # "high": weights as hi + lo operand pairs (vgen_amd/unet.py)
+        assert self.precision in ("fast", "high")
         self._packed = None
         self._attn_qb = None          # query-block override of the mid attention (tests force several blocks)
         if pretrained is not None:
@@ -201,6 +203,10 @@ class AutoencoderKL(nn.Module):
     # -- packing ---------------------------------------------------------------------------------
     @torch.no_grad()
     def pack(self):
+        with split_weights(self.precision == "high"):
+            return self._pack()
+
+    def _pack(self):
         dt = self.compute_dtype
         P = {}
         for name, m in self.named_modules():
@@ -209,10 +215,12 @@ class AutoencoderKL(nn.Module):
                 d = {"gn1": (_f32(m.norm1.weight), _f32(m.norm1.bias)),
                      "conv1": (pack_conv3x3(m.conv1.weight, dt), _f32(m.conv1.bias)),
                      "gn2": (_f32(m.norm2.weight), _f32(m.norm2.bias))}
-                w2, b2 = pack_conv3x3(m.conv2.weight, dt), _f32(m.conv2.bias)
+                b2 = _f32(m.conv2.bias)
                 if m.cin != m.cout:
-                    w2 = torch.cat([w2, pack_linear(m.nin_shortcut.weight, dt)], 1).contiguous()
+                    w2 = _w16_cat([pack_conv3x3(m.conv2.weight), pack_linear(m.nin_shortcut.weight)], dt)
                     b2 = (b2 + _f32(m.nin_shortcut.bias)).contiguous()
+                else:
+                    w2 = pack_conv3x3(m.conv2.weight, dt)
                 d["conv2"] = (w2, b2)
                 P[name] = d
             elif isinstance(m, _AttnBlockP):
