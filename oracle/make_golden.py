@@ -370,6 +370,37 @@ def make_blocks(R):
     print("blocks", len(recs), [(r["name"], r["kind"], r["src"]) for r in recs][:8], "...")
 
 
+def make_vae_blocks(R):
+    """Per-block goldens of the reference's tiny AutoencoderKL (encode of the fixture image + decode of the fixture
+    latent): every ResnetBlock, AttnBlock, Upsample and Downsample with its input and output — all blocks are
+    sequential, so a block's input is the previous record's output (or the stem's output, stored)."""
+    g = torch.load(os.path.join(GOLD, "vae_tiny.pt"), weights_only=False)
+    vae = R["AUTO_ENCODER"].build(dict(type="AutoencoderKL", ddconfig=g["ddconfig"], embed_dim=4)).eval()
+    vae.load_state_dict(torch_ref.synth_state_dict(g["shapes"], seed=g["seed"]), strict=True)
+    kinds = ("ResnetBlock", "AttnBlock", "Upsample", "Downsample")
+    recs, outs = [], []
+
+    def hook(name):
+        def fn(mod, args, out):
+            xin = args[0].float()
+            src = len(outs) - 1 if outs and outs[-1].shape == xin.shape and torch.equal(outs[-1], xin) else None
+            recs.append(dict(name=name, kind=type(mod).__name__, src=src, x=None if src is not None else xin.clone()))
+            outs.append(out.float().clone())
+        return fn
+
+    hs = [m.register_forward_hook(hook(n)) for n, m in vae.named_modules() if type(m).__name__ in kinds]
+    gen = torch.Generator("cpu").manual_seed(5)
+    img = torch.randn(1, 3, 48, 32, generator=gen)          # small on purpose: 24 blocks x (in, out) stay ~2 MB
+    z = torch.randn(1, 4, 6, 4, generator=gen)
+    with torch.no_grad():
+        vae.encode(img)
+        vae.decode(z)
+    for h in hs:
+        h.remove()
+    torch.save(dict(recs=recs, outs=outs, img=img, z=z), os.path.join(GOLD, "vae_blocks_tiny.pt"))
+    print("vae blocks", len(recs), [(r["name"], r["kind"], r["src"]) for r in recs if r["src"] is None])
+
+
 def make_yardstick(R, full):
     """How far the reference's OWN mixed-precision arithmetic (amp.autocast, the mode its engines run:
     `use_fp16: True`, inference_text2video_entrance.py:197) lands from its fp32 forward on the fixtures' inputs —
@@ -442,6 +473,9 @@ def main():
         return
     if args.only == "blocks":
         make_blocks(R)
+        return
+    if args.only == "vae_blocks":
+        make_vae_blocks(R)
         return
     torch.manual_seed(0)
 

@@ -45,3 +45,39 @@ def run_blocks(dtname, dev):
         assert (want.shape[2], want.shape[3]) == (H, W) and o.shape == (want.shape[0] * H * W, want.shape[1]), r["name"]
         res[r["name"]] = (r["kind"], rel_l2(o.float().cpu(), rows(want).cpu()))
     return res
+
+
+def run_vae_blocks(dtname, dev):
+    """Every ResnetBlock / AttnBlock / Upsample / Downsample of the reference's tiny AutoencoderKL (encoder and decoder)
+    alone on the reference's input (tests/golden/vae_blocks_tiny.pt) -> {name: (kind, rel-L2)}"""
+    from vgen_amd import ops
+    from vgen_amd.vae import AutoencoderKL, _ResnetBlockP, _AttnBlockP, _ResampleP
+    g0, g = gold("vae_tiny.pt"), gold("vae_blocks_tiny.pt")
+    v = AutoencoderKL(ddconfig=g0["ddconfig"], embed_dim=4, compute_dtype=dtname).eval()
+    v.load_state_dict(torch_ref.synth_state_dict(g0["shapes"], seed=g0["seed"]), strict=True)
+    v = v.to(dev)
+    v.pack()
+    be, dt, P = ops.backend(), v.compute_dtype, v._packed
+    rows = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous().to(dev)
+    res = {}
+    for i, r in enumerate(g["recs"]):
+        xin = r["x"] if r["src"] is None else g["outs"][r["src"]]
+        n, _, H, W = xin.shape
+        mod = v.get_submodule(r["name"])
+        x = rows(xin)
+        if isinstance(mod, _ResnetBlockP):
+            o = v._resnet(mod, x, n, H, W)
+        elif isinstance(mod, _AttnBlockP):
+            o = v._attn(mod, x, n, H, W)
+        elif isinstance(mod, _ResampleP):
+            a = be.act_cast(x, 0, dt)
+            if r["kind"] == "Upsample":
+                o, H, W = v._conv(a, P[mod._pname], n, H, W, x.shape[1], ups=1)
+            else:
+                o, H, W = v._conv(a, P[mod._pname], n, H, W, x.shape[1], stride=2, pad=0)
+        else:
+            raise TypeError(type(mod))
+        want = g["outs"][i]
+        assert tuple(want.shape[2:]) == (H, W), (r["name"], want.shape, H, W)
+        res[r["name"]] = (r["kind"], rel_l2(o.float().cpu(), rows(want).cpu()))
+    return res

@@ -51,6 +51,14 @@ def test_every_block_alone_vs_reference_golden(emu_backend):
     assert not bad, bad
 
 
+def test_every_vae_block_alone_vs_reference_golden(emu_backend):
+    from block_cases import run_vae_blocks
+    res = run_vae_blocks("fp16", "cpu")
+    assert len(res) == 24 and {k for k, _ in res.values()} == {"ResnetBlock", "AttnBlock", "Upsample", "Downsample"}
+    bad = {n: v for n, v in res.items() if not v[1] < 2e-3}
+    assert not bad, bad
+
+
 def test_high_precision_mode_splits_every_packed_weight(emu_backend):
     """precision="high": the packers attach the rounding residual to every 16-bit weight operand (W_hi + W_lo == the
     fp32 weight to ~2^-21), linear launches take it as a second K segment and tap gathers as a second launch — checked
