@@ -382,12 +382,37 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   auto read_phase = [&](int stage, auto prefetch_tag, int stage_pf) __attribute__((always_inline)) {
     constexpr bool prefetch = decltype(prefetch_tag)::value;
     static_assert(!PP || MH == 1, "ping-pong keeps a whole K-tile of fragments in registers");
-    read_w(stage);
-    read_x(stage, 0);
+    // fragment reads and DMA issues interleaved: a DMA instruction parks the wave on the CU's texture-address path
+    // while the LDS serves the reads issued just before it (issued as two blocks, reads then DMAs, the two phases
+    // simply added up: profiles/r02_tapgemm_rphase_ablation.json).  conv 57344x320x2880 144.8 -> 135.7 us, linear
+    // 57344x2560x2560 781 -> 740 us; whole step -0.8 % in same-box A/Bs (34.35 -> 34.05 ms, 30.83 -> 30.59 ms);
+    // 2 or 3 reads per DMA, DMA leading or trailing its group: all within 0.2 %.
+    const unsigned char* bw = smem + stage * STAGE_BYTES + BM * ROW_BYTES + wn * WTN * ROW_BYTES + rd_row;
+    const unsigned char* bx = smem + stage * STAGE_BYTES + (wm * WTM) * ROW_BYTES + rd_row;
+    constexpr int NR = KS * (NF + MF);                 // fragment reads per wave and K-tile
+    constexpr int EVERY = (NR + NP) / (NP + 1) > 0 ? (NR + NP) / (NP + 1) : 1;   // reads between two DMA issues (3)
+    int piece = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+      const int ks = r / (NF + MF), q = r % (NF + MF);
+      const int co = ((ks * 4 + lq) ^ sw) << 4;
+      if (q < NF) wf[ks][q] = *(const u32x4*)(bw + q * 16 * ROW_BYTES + co);
+      else xf[ks][q - NF] = *(const u32x4*)(bx + (q - NF) * 16 * ROW_BYTES + co);
+      if (prefetch && (r % EVERY) == EVERY - 1 && piece < NP) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (piece < LPT) glds16(pc[piece], piece_dst(stage_pf, piece));
+        else if (RBT > 0 && w_tail) glds16(pc[NP - 1], piece_dst(stage_pf, NP - 1));
+        ++piece;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
     if (prefetch) {
 #pragma unroll
-      for (int j = 0; j < LPT; ++j) glds16(pc[j], piece_dst(stage_pf, j));
-      if (RBT > 0 && w_tail) glds16(pc[NP - 1], piece_dst(stage_pf, NP - 1));
+      for (int j = 0; j < NP; ++j)
+        if (j >= piece) {
+          if (j < LPT) glds16(pc[j], piece_dst(stage_pf, j));
+          else if (RBT > 0 && w_tail) glds16(pc[NP - 1], piece_dst(stage_pf, NP - 1));
+        }
       advance();
     }
   };
