@@ -413,7 +413,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
           if (j < LPT) glds16(pc[j], piece_dst(stage_pf, j));
           else if (RBT > 0 && w_tail) glds16(pc[NP - 1], piece_dst(stage_pf, NP - 1));
         }
-      advance();
     }
   };
   auto mfma_phase = [&]() __attribute__((always_inline)) {
@@ -460,6 +459,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
       __builtin_amdgcn_sched_barrier(0);
       mfma_phase();
       __builtin_amdgcn_sched_barrier(0);
+      // the pointer step of this wave's next DMA issue runs here, behind the queued MFMAs: a K-step lasts two READ
+      // phases (the matrix phase of one wave group hides under the read phase of the other), so VALU work moved
+      // out of the read phase shortens the step twice over
+      if (decltype(prefetch_tag)::value) advance();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       rotate();
