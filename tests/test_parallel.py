@@ -163,3 +163,64 @@ def test_partition_single_process_is_identity():
     outs = [torch.full((2, 3), float(i)) for i in range(4)]
     got = p.gather_units(outs, 4, outs[0])
     assert all(torch.equal(a, b) for a, b in zip(got, outs))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# the same partition with the HIP kernels: two ranks sharing ONE GPU over gloo (RCCL refuses two ranks per device; the
+# development boxes have one GPU) — sessions, hipGraph capture under an initialised process group, the all-gather of
+# device tensors and the redundant fused update all execute as they would with one rank per GPU.
+def _worker_unet_gpu(rank, world, port, P, q):
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from vgen_amd import ops
+    from vgen_amd.diffusion import DiffusionDDIM
+    from vgen_amd.parallel import UnitPartition
+    ops.set_backend(None)
+    assert ops.backend().name == "hip"
+    m, noise, kw = _unet_case(P)
+    dev = torch.device("cuda", 0)
+    m = m.to(dev)
+    kw = [{k: v.to(dev) for k, v in d.items()} for d in kw]
+    d = DiffusionDDIM(schedule="cosine", schedule_param=dict(num_timesteps=1000, cosine_s=0.008, zero_terminal_snr=True),
+                      mean_type="v", var_type="fixed_small")
+    d.partition = UnitPartition()
+    out = d.ddim_sample_loop(noise.to(dev), m, kw, guide_scale=9.0, ddim_timesteps=4, eta=0.0)
+    sess = next(iter(d.partition.sessions._items.values()))
+    q.put((rank, out.cpu(), len(d.partition.sessions._items), bool(sess.use_graph and sess._graphs), d.partition.layout(P, 2)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [1, 2])
+def test_unit_partition_world2_on_one_gpu(P):
+    from vgen_amd import ops
+    from vgen_amd.diffusion import DiffusionDDIM
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_unet_gpu, args=(r, 2, port, P, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    prev = ops.set_backend(None)
+    try:
+        m, noise, kw = _unet_case(P)
+        dev = torch.device("cuda", 0)
+        m = m.to(dev)
+        kw = [{k: v.to(dev) for k, v in d.items()} for d in kw]
+        d = DiffusionDDIM(schedule="cosine", schedule_param=dict(num_timesteps=1000, cosine_s=0.008, zero_terminal_snr=True),
+                          mean_type="v", var_type="fixed_small")
+        ref = d.ddim_sample_loop(noise.to(dev), m, kw, guide_scale=9.0, ddim_timesteps=4, eta=0.0).cpu()
+    finally:
+        ops.set_backend(prev)
+    assert torch.equal(res[0][1], res[1][1])                       # every rank ends with the same latents
+    assert res[0][2] == 1 and res[1][2] == 1 and res[0][3] and res[1][3]   # one session per rank, replayed as a graph
+    assert res[0][4] == ("prompt" if P == 2 else "unit")
+    assert torch.isfinite(res[0][1]).all() and rel_l2_(res[0][1], ref) < 1e-2   # noise floor of re-batched 16-bit GEMMs
