@@ -8,7 +8,9 @@ A "step" = one classifier-free-guidance DDIM denoise step of the t2v configurati
 (BASELINE.json configs[1]: latent [1,4,16,32,56] = 16 frames 448x256, 77x1024 context, guide 9,
 UNetSD_T2VBase 1411 M parameters): two UNet forwards (evaluated as one batch of 2 units) + the
 fused CFG/DDIM update, with all inputs resident in HBM.  Synthetic latents/context, seeded
-random-init weights (no checkpoints offline).
+random-init weights (no checkpoints offline) — for the t2v configuration the very weights of the golden
+fixture tests/golden/unet_t2v_full.pt (vgen_amd/synth.py), so the model that is timed is the model whose
+output is compared with the reference's.
 
 The timed region calls the PUBLIC sampler API the engines use, step by step:
 `DiffusionDDIM.ddim_sample(xt, t, model, [cond, uncond], guide_scale=9, ddim_timesteps=50, eta=0)`
@@ -17,36 +19,41 @@ each call's x_{t-1} fed to the next, t walking the 50-step DDIM schedule.  Under
 session (vgen_amd/session.py) replays one hipGraph per step; the untimed setup does two steps (eager
 warm-up + capture), like weight loading.
 
-Operand dtype: fp16 by default — the arithmetic the reference itself runs (`use_fp16: True`, autocast) and the
-16-bit type whose UNet output is closest to the fp32 reference (profiles/r02_parity.json); `--dtype bf16`
-runs BASELINE.json's literal "bf16" (same MFMA rate, 8x the rounding error).
+HEADLINE MODE = the mode that meets the north-star's tolerance: fp16 operands, precision="high" (every packed
+weight as a W_hi + W_lo pair, one dual-W tap-GEMM launch per layer): UNet output <= 1e-3 rel-L2 of the reference's
+fp32 forward.  `parity.unet_rel_l2` is COMPUTED IN THIS RUN: the timed model evaluates the golden fixture's input
+and is compared with the reference's recorded fp32 output.  `variants` carries the same two measurements (timed
+steps + parity, in this run) for the single-pass modes: fp16/fast (the reference's own autocast arithmetic) and
+bf16/fast (BASELINE.json's literal "bf16") — both faster, both outside 1e-3.
 
-N > 1 (weak scaling): P = N prompts in flight -> 2N units spread over the ranks (unit u -> rank
-u % N), ONE all-gather of the unit outputs per step (RCCL), every rank applies the cheap update for
-all prompts.  value = prompts * steps / max-over-ranks time.  `--partition` runs that code path at N = 1.
+N > 1 (weak scaling): P = N prompts in flight -> 2N units spread over the ranks, ONE all-gather of the unit
+outputs per step (RCCL), every rank applies the cheap update for all prompts.  value = prompts * steps /
+max-over-ranks time.  `--partition` runs that code path at N = 1.
 
-`--config {i2vgen,sr600,tft2v896,tft2v32f,videolcm}` runs the other BASELINE.json shapes through
-the same API (random-init weights of that architecture; see CONFIGS).
+`--config {i2vgen,sr600,tft2v896,tft2v32f,videolcm}` runs the other BASELINE.json shapes through the
+same API (random-init weights of that architecture; see CONFIGS).  `--config sr600` times the SR600 stage's own
+samplers: `GaussianDiffusion.sample(solver='dpmpp_2m_sde')` CFG steps (value) and the DDIM-inversion forwards
+(`inversion` object), tools/inferences/inference_tft2v_sr600_entrance.py:284-308.
 
-Extra objects on the JSON line:
-  roofline     — dominant kernel (tap-GEMM, MFMA-bound): algorithmic FLOP per launch / average launch
-                 duration, measured with HIP events on the launch stream in an instrumented eager pass of
-                 the same step; peak = 2.5 PFLOP/s dense 16-bit MFMA.  `traffic` = HBM-side bytes per launch
-                 from the committed rocprofv3 PMC passes of this command (profiles/, tools/collect_evidence.sh).
+Objects on the JSON line — every number is measured in this run unless its key says `committed`:
+  parity       — see above.
+  roofline     — dominant kernel (tap-GEMM, MFMA-bound): algorithmic FLOP per launch (2 M N K of the product each
+                 launch computes; a dual-W launch executes twice the MFMAs for it) / average launch duration, measured
+                 with HIP events on the launch stream in an instrumented eager pass of the same step; peak = 2.5
+                 PFLOP/s dense 16-bit MFMA.  `committed` sub-object: HBM-side bytes per launch and MFMA-busy fraction
+                 from the committed rocprofv3 PMC passes (profiles/), which cannot be read from inside the process.
   hbm_kernels  — GroupNorm / LayerNorm launches of the same pass: algorithmic bytes / time vs 8 TB/s.
-  cpu_baseline — the oracle (CPU port of the reference forward, oracle/torch_ref.py) timed on the
-                 host cores on a bounded sample, scaled to a full step; rank 0 at N=1.
+  cpu_baseline — the CPU path timed on the host cores on a bounded sample (one full-size forward), scaled to a
+                 step; `kind` = "reference" when the reference tree is present (its own modules through
+                 oracle/ref_import.py), else "port" (oracle/torch_ref.py); rank 0 at N=1.
   vae / e2e    — AutoencoderKL decode frames/s; a whole video (50-step ddim_sample_loop + 16-frame decode).
-  parity       — UNet rel-L2 vs the reference's fp32 forward for this dtype (from the committed GPU-test record).
 
-`model_tflops_per_s` / `frac_of_mfma_peak` count the REFERENCE's work per step (2 forwards x 8.665 TFLOP): the
-throughput in the reference's own units.  The kernels execute slightly less — the cond / uncond pair shares the layers
-ahead of the first cross-attention — which `roofline.tapgemm_tflop_per_step` (measured) shows; `roofline.achieved` is
-executed FLOP / measured kernel time.
+`model_tflops_per_s` / `frac_of_mfma_peak` count the REFERENCE's work per step (2 forwards x 8.665 TFLOP).
 """
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -65,9 +72,16 @@ VAE_SD = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch
               ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)
 DDIM = dict(schedule="cosine", schedule_param=dict(num_timesteps=1000, cosine_s=0.008, zero_terminal_snr=True),
             mean_type="v", loss_type="mse", var_type="fixed_small", rescale_timesteps=False)
+# configs/tft2v_vcomposer_32frames_sr600_infer.yaml:38-60 of the reference
+SR600_DIFF = dict(
+    reverse_diffusion=dict(schedule="cosine", mean_type="v", schedule_param=dict(num_timesteps=1000, zero_terminal_snr=True)),
+    forward_diffusion=dict(schedule="logsnr_cosine_interp", mean_type="v",
+                           schedule_param=dict(num_timesteps=1000, zero_terminal_snr=True, scale_min=2.0, scale_max=4.0)))
 VAE_DEC_TFLOP = 1.092       # per 256x448 frame
 PEAK_TFLOPS = 2500.0        # dense bf16/fp16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0
+TOLERANCE = 1e-3            # north_star: UNet output within 1e-3 rel-L2 of the reference
+GOLDEN_T2V = os.path.join(ROOT, "tests", "golden", "unet_t2v_full.pt")
 
 # name -> (model class path, ctor kwargs, latent [C,F,H,W], units per step G, UNet forward TFLOP,
 #          extra conditioning builder, description)
@@ -81,7 +95,8 @@ CONFIGS = {
                         "77+64+4 ctx tokens, local-image stem channels"),
     "sr600": dict(cls="unet.UNetSD_SR600", cfg=dict(UNET_T2V, use_scale_shift_norm=True, inpainting=True),
                   latent=(4, 32, 90, 160), G=2, tflop=185.80,
-                  desc="sr600 32x1280x720 latent [1,4,32,90,160], CFG step (2 UNetSD_SR600 fwd + fused update), "
+                  desc="sr600 32x1280x720 latent [1,4,32,90,160], DPM-Solver++(2M) SDE CFG step "
+                       "(GaussianDiffusion.sample: 2 UNetSD_SR600 fwd + guide_rescale + solver update), "
                        "pad-(2,1) downsample / cropped upsample / FreeU"),
     "tft2v896": dict(cls="unet_videolcm.UNetSD_TFT2V", cfg=dict(UNET_T2V, num_tokens=4), comps=["text", "image"],
                      latent=(4, 16, 64, 112), G=2, tflop=38.97,
@@ -110,21 +125,42 @@ def randomize_(module, seed):
                 p.copy_(0.1 * torch.randn(p.shape, generator=g, device=p.device))
 
 
-def build_model(name, dev, dtype, precision="fast"):
+def model_class(name):
     import importlib
+    modname, clsname = CONFIGS[name]["cls"].split(".")
+    return getattr(importlib.import_module("vgen_amd." + modname), clsname)
+
+
+def build_model(name, dev, dtype, precision="high", state_dict=None):
+    """The model of config `name` on `dev`, packed.  state_dict: fp32 CPU parameters to load (the golden fixture's
+    weights for t2v); None = device-side seeded random init."""
     import types
     c = CONFIGS[name]
-    modname, clsname = c["cls"].split(".")
-    cls = getattr(importlib.import_module("vgen_amd." + modname), clsname)
+    cls = model_class(name)
     kw = dict(c["cfg"])
     if "comps" in c:
         kw["config"] = types.SimpleNamespace(video_compositions=c["comps"], resolution=[c["latent"][3] * 8, c["latent"][2] * 8])
-    with torch.device(dev):
-        model = cls(**kw, compute_dtype=dtype, precision=precision)
-    model.eval()
-    randomize_(model, 0)
+    if state_dict is not None:
+        with torch.device("meta"):
+            model = cls(**kw, compute_dtype=dtype, precision=precision)
+        model = model.to_empty(device="cpu").eval()
+        model.load_state_dict(state_dict, strict=True, assign=True)
+        model = model.to(dev)
+    else:
+        with torch.device(dev):
+            model = cls(**kw, compute_dtype=dtype, precision=precision)
+        model.eval()
+        randomize_(model, 0)
     model.pack()
     return model
+
+
+def drop_masters(model, dev):
+    """fp32 masters are not needed for sampling once the operands are packed (the variants' condition stems run on
+    theirs, so only the t2v trunk drops them)."""
+    for p in model.parameters():
+        p.data = torch.empty(0, device=dev)
+    torch.cuda.empty_cache()
 
 
 def conditioning(name, model, P, dev, gen):
@@ -147,6 +183,59 @@ def conditioning(name, model, P, dev, gen):
     return [kc, ku] if c["G"] == 2 else [kc]
 
 
+def golden_parity(model, gold, dev):
+    """rel-L2 of `model`'s forward on the golden fixture's input vs the reference's recorded fp32 output."""
+    gen = torch.Generator("cpu").manual_seed(gold["input_seed"])
+    x = torch.randn(1, 4, 16, 32, 56, generator=gen)
+    y = torch.randn(1, 77, 1024, generator=gen)
+    with torch.no_grad():
+        out = model(x.to(dev), gold["t"].to(dev), y=y.to(dev)).float().cpu()
+    ref = gold["out"].float()
+    return float((out - ref).norm() / ref.norm())
+
+
+class StepTimer:
+    """Times `steps` calls of the public per-step sampler API (after 2 setup calls and `warmup` calls)."""
+
+    def __init__(self, diff, model, xt0, mkw, guide, dev, P):
+        self.diff, self.model, self.xt0, self.mkw, self.guide, self.dev, self.P = diff, model, xt0, mkw, guide, dev, P
+        self.steps_all = (1 + torch.arange(0, 1000, 20)).clamp(0, 999).flip(0).tolist()
+        self.t_bufs = {s: torch.full((P,), s, dtype=torch.long, device=dev) for s in self.steps_all}
+
+    def t_of(self, i):
+        return self.t_bufs[self.steps_all[i % len(self.steps_all)]]
+
+    def step(self, xt, i):
+        return self.diff.ddim_sample(xt, self.t_of(i), self.model, self.mkw, guide_scale=self.guide, ddim_timesteps=50,
+                                     eta=0.0)[0]
+
+    def run(self, steps, warmup, world=1):
+        import torch.distributed as dist
+        xt = self.xt0
+        for i in range(2):                                  # untimed setup: eager warm-up pass + graph capture
+            xt = self.step(xt, i)
+        xt = self.xt0
+        for i in range(warmup):
+            xt = self.step(xt, i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            xt = self.step(xt, warmup + i)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt_s = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt_s], device=self.dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_s = float(tt.item())
+        return dt_s, xt
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -154,14 +243,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16"])
     ap.add_argument("--config", default="t2v", choices=sorted(CONFIGS))
-    ap.add_argument("--precision", default="fast", choices=["fast", "high"],
-                    help="high: every packed weight carries its 16-bit rounding residual as a second operand (UNet rel-L2 "
-                         "<= 1e-3 from the reference's fp32 forward; ~2x the tap-GEMM time) — not the headline mode")
+    ap.add_argument("--precision", default="high", choices=["fast", "high"],
+                    help="high (default): packed weights as W_hi + W_lo pairs, dual-W tap-GEMM launches — the mode whose "
+                         "UNet output is within 1e-3 rel-L2 of the reference's fp32 forward; fast: one 16-bit operand pair "
+                         "per GEMM (the reference's autocast arithmetic; 1.33e-3)")
+    ap.add_argument("--variants", default="fp16/fast,bf16/fast",
+                    help="other dtype/precision modes timed + parity-checked after the headline mode (t2v, N = 1); '' = none")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--partition", action="store_true",
                     help="use the multi-GPU code path (UnitPartition: session over the local units + eager "
                          "gather/update) even at --gpus 1")
@@ -178,6 +271,7 @@ def main():
     from vgen_amd import ops
     from vgen_amd.diffusion import DiffusionDDIM
     from vgen_amd.parallel import UnitPartition
+    from vgen_amd.synth import seeded_state_dict
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -198,11 +292,14 @@ def main():
     cfg = CONFIGS[args.config]
     C, F, H, W = cfg["latent"]
     G = cfg["G"]
-    model = build_model(args.config, dev, args.dtype, args.precision)
-    if args.config == "t2v":                          # fp32 masters are not needed for sampling (the variants'
-        for p in model.parameters():                  # condition stems run on theirs)
-            p.data = torch.empty(0, device=dev)
-        torch.cuda.empty_cache()
+    gold = sd = None
+    if args.config == "t2v":
+        # the golden fixture's weights: shapes + seed -> the tensors the reference's fp32 forward was recorded on
+        gold = torch.load(GOLDEN_T2V, map_location="cpu", weights_only=False)
+        sd = seeded_state_dict(gold["shapes"], seed=gold["seed"])
+    model = build_model(args.config, dev, args.dtype, args.precision, state_dict=sd)
+    if args.config == "t2v":
+        drop_masters(model, dev)
 
     diff = DiffusionDDIM(**DDIM)
     diff.rng_parity = False
@@ -212,49 +309,59 @@ def main():
     kw = conditioning(args.config, model, P, dev, g)
     guide = 9.0 if G == 2 else None
     mkw = kw if G == 2 else kw[0]
-    steps_all = (1 + torch.arange(0, 1000, 20)).clamp(0, 999).flip(0).tolist()
     part = UnitPartition() if (world > 1 or args.partition) else None
     diff.partition = part
-    t_bufs = {}
 
-    def t_of(i):
-        s = steps_all[i % len(steps_all)]
-        if s not in t_bufs:
-            t_bufs[s] = torch.full((P,), s, dtype=torch.long, device=dev)
-        return t_bufs[s]
-
-    for i in range(len(steps_all)):                     # untimed: the 50 timestep tensors of the schedule
-        t_of(i)
-
-    def step(xt, i):
-        return diff.ddim_sample(xt, t_of(i), model, mkw, guide_scale=guide, ddim_timesteps=50, eta=0.0)[0]
-
-    xt = xt0
-    for i in range(2):                                  # untimed setup: eager warm-up pass + graph capture
-        xt = step(xt, i)
-    xt = xt0
-    for i in range(args.warmup):
-        xt = step(xt, i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        xt = step(xt, args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt_s = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt_s], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt_s = float(tt.item())
+    inversion = None
+    if args.config == "sr600":
+        # the SR600 stage's own samplers (inference_tft2v_sr600_entrance.py:284-308): DDIM inversion = single forwards
+        # without CFG at t = 0, 23, ...; then sample(solver='dpmpp_2m_sde') CFG steps with guide_rescale 0.3
+        from vgen_amd.diffusion_gauss import DiffusionDDIMSR
+        srd = DiffusionDDIMSR(**SR600_DIFF)
+        srd.reverse_diffusion.partition = srd.forward_diffusion.partition = part
+        zero_kw = {"y": kw[1]["y"]}
+        K = args.steps
+        srd.reverse_diffusion.ddim_reverse_sample_loop(xt0, model, zero_kw, guide_scale=None, ddim_timesteps=2,
+                                                       reverse_steps=46)                 # setup: session + capture
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        noised = srd.reverse_diffusion.ddim_reverse_sample_loop(xt0, model, zero_kw, guide_scale=None,
+                                                                ddim_timesteps=K, reverse_steps=23 * K)
+        torch.cuda.synchronize()
+        inv_s = time.perf_counter() - t0
+        inversion = {"forwards": K, "seconds": round(inv_s, 4), "forwards_per_sec": round(K / inv_s, 4),
+                     "api": "GaussianDiffusion.ddim_reverse_sample_loop (1 UNet fwd per step, no CFG)"}
+        smp = dict(model=model, model_kwargs=kw, guide_scale=9.0, guide_rescale=0.3, solver="dpmpp_2m_sde",
+                   t_max=699, t_min=0, discretization="trailing", seed=8888)
+        srd.forward_diffusion.sample(noise=noised, steps=2, **smp)                        # setup
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        xt = srd.forward_diffusion.sample(noise=noised, steps=K, **smp)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt_s = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt_s], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt_s = float(tt.item())
+        timer = StepTimer(diff, model, xt0, mkw, guide, dev, P)
+        api = "GaussianDiffusion.sample(solver='dpmpp_2m_sde', steps=K) — K CFG model evaluations + solver updates, whole loop timed"
+        cache = srd.forward_diffusion.sessions
+    else:
+        timer = StepTimer(diff, model, xt0, mkw, guide, dev, P)
+        dt_s, xt = timer.run(args.steps, args.warmup, world)
+        api = "DiffusionDDIM.ddim_sample per step (public sampler API; cached sampling session underneath)"
+        cache = part.sessions if part is not None else diff.sessions
     finite = bool(torch.isfinite(xt).all())
     xt_absmax = float(xt.float().abs().nan_to_num(nan=float("inf")).max())
     sess = None
-    cache = part.sessions if part is not None else diff.sessions
+    if part is not None:
+        cache = part.sessions
     if cache is not None and cache._items:
         sess = next(iter(cache._items.values()))
 
@@ -265,26 +372,32 @@ def main():
         "ms_per_step": round(1e3 * dt_s / args.steps, 3), "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": cfg["desc"], "name": args.config,
-                   "prompts_in_flight": P, "units_per_step": G * P,
-                   "api": "DiffusionDDIM.ddim_sample per step (public sampler API; cached sampling session underneath)",
+                   "prompts_in_flight": P, "units_per_step": G * P, "api": api,
                    "parallelism": "single GPU" if world == 1 else
                    f"unit partition over {world} ranks, 1 all-gather/step ({args.backend}{', all ranks on one device: functional test' if one_dev else ''})",
                    "hipgraph": bool(sess is not None and sess.use_graph and sess._graphs) and
-                   ("whole step" if part is None else "local units' forward"),
-                   "precision": args.precision},
+                   ("whole step" if (part is None and args.config != "sr600") else "units' forward"),
+                   "precision": args.precision,
+                   "weights": "seeded synthetic (vgen_amd/synth.py)" + (": the golden fixture's" if gold is not None else "")},
         "finite": finite, "latent_absmax_after_timed_steps": xt_absmax,
         "model_tflops_per_s": round(G * cfg["tflop"] * steps_per_s, 2),
         "frac_of_mfma_peak": round(G * cfg["tflop"] * steps_per_s / world / PEAK_TFLOPS, 4),
     }
-    ppath = os.path.join(ROOT, "profiles", "r02_parity.json")
-    if os.path.exists(ppath) and args.config == "t2v":
-        pj = json.load(open(ppath))
-        key = f"unet_t2v_full/{args.dtype}" + ("/high" if args.precision == "high" else "")
-        if key in pj:
-            res["parity"] = {"dtype": args.dtype, "unet_rel_l2": pj[key],
-                             "reference_own_autocast_rel_l2": pj.get(f"reference_autocast/{args.dtype}"),
-                             "source": "profiles/r02_parity.json (tests/test_gpu_model.py on MI355X, full-size golden "
-                                       "from the reference's fp32 forward)"}
+    if inversion is not None:
+        res["inversion"] = inversion
+
+    # ---- parity of the model that was just timed, computed here --------------------------------------------
+    if rank == 0 and gold is not None and not args.no_parity:
+        err = golden_parity(model, gold, dev)
+        res["parity"] = {"unet_rel_l2": err, "tolerance": TOLERANCE, "within_tolerance": bool(err <= TOLERANCE),
+                         "dtype": args.dtype, "precision": args.precision, "measured_in_this_run": True,
+                         "golden": "tests/golden/unet_t2v_full.pt: the reference's fp32 UNetSD_T2VBase forward on the "
+                                   "same seeded weights and input (oracle/make_golden.py)"}
+        ypath = os.path.join(ROOT, "tests", "golden", "autocast_yardstick.json")
+        if os.path.exists(ypath):
+            val = json.load(open(ypath)).get(f"unet_t2v_full/{args.dtype}")
+            if val is not None:      # how far the reference's OWN autocast forward lands from its fp32 forward (committed fixture)
+                res["parity"]["committed_reference_own_autocast_rel_l2"] = val
 
     # ---- roofline of the dominant kernel (instrumented eager pass, same step) ----------------------
     if rank == 0 and not args.no_roofline:
@@ -294,11 +407,12 @@ def main():
         xs = xt0[:1].clone()
         kw1 = [{k: (v[:1] if torch.is_tensor(v) else v) for k, v in d.items()} for d in kw]
         mk1 = kw1 if G == 2 else kw1[0]
-        d0.ddim_sample(xs, t_of(0)[:1], model, mk1, guide_scale=guide, ddim_timesteps=50, eta=0.0)
+        t1 = timer.t_of(0)[:1]
+        d0.ddim_sample(xs, t1, model, mk1, guide_scale=guide, ddim_timesteps=50, eta=0.0)
         ops.KERNEL_PROFILE = []
         torch.cuda.synchronize()
         torch.cuda._sleep(int(4e8))     # let the host run ahead so event pairs bracket GPU time only
-        d0.ddim_sample(xs, t_of(0)[:1], model, mk1, guide_scale=guide, ddim_timesteps=50, eta=0.0)
+        d0.ddim_sample(xs, t1, model, mk1, guide_scale=guide, ddim_timesteps=50, eta=0.0)
         torch.cuda.synchronize()
         allrecs = ops.KERNEL_PROFILE
         ops.KERNEL_PROFILE = None
@@ -314,10 +428,11 @@ def main():
             a[1] += r[1].elapsed_time(r[2])
             a[2] += r[3]
         if args.dump_shapes:
+            tag = f"{args.config}_{args.dtype}_{args.precision}"
             orows = sorted(([list(k), v[0], round(v[1], 4), round(v[2] / (v[1] * 1e-3) / 1e9, 1)] for k, v in other.items()),
                            key=lambda r: -r[2])
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-            with open(os.path.join(ROOT, "gpurun_out", f"other_shapes_{args.config}.json"), "w") as f:
+            with open(os.path.join(ROOT, "gpurun_out", f"other_shapes_{tag}.json"), "w") as f:
                 json.dump({"cols": ["(op,shape...)", "launches", "ms", "GB/s or GFLOP/s"], "rows": orows}, f, indent=0)
             agg = {}
             for r, m in zip(recs, ms):
@@ -327,29 +442,38 @@ def main():
                 a[2] += r[3]
             rows = sorted(([list(k), v[0], round(v[1], 4), round(v[2] / (v[1] * 1e-3) / 1e12, 1)] for k, v in agg.items()),
                           key=lambda r: -r[2])
-            with open(os.path.join(ROOT, "gpurun_out", f"tapgemm_shapes_{args.config}.json"), "w") as f:
-                json.dump({"cols": ["(mode,M,N,K,epi,out)", "launches", "ms", "TFLOP/s"], "rows": rows}, f, indent=0)
+            with open(os.path.join(ROOT, "gpurun_out", f"tapgemm_shapes_{tag}.json"), "w") as f:
+                json.dump({"cols": ["(mode,M,N,K,epi,out)", "launches", "ms", "algorithmic TFLOP/s"], "rows": rows}, f, indent=0)
         tot_ms, tot_fl = sum(ms), sum(fl)
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
+        ndw = sum(1 for r in recs if str(r[4][5]).endswith("+dw"))
         res["roofline"] = {"kernel": "tapgemm_kernel", "bound": "mfma", "achieved": round(ach, 2),
                            "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS, 4),
-                           "traffic": None, "launches_per_step": len(recs),
+                           "traffic": None, "launches_per_step": len(recs), "dual_w_launches": ndw,
                            "avg_launch_us": round(1e3 * tot_ms / max(len(recs), 1), 2),
                            "avg_gflop_per_launch": round(tot_fl / max(len(recs), 1) / 1e9, 3),
                            "tapgemm_ms_per_step": round(tot_ms, 3),
-                           # FLOP the kernel actually executed in one step (the CFG pair shares the layers ahead of the first
-                           # cross-attention, so this is a few % below the reference's 2 x forward count used in model_tflops_per_s)
-                           "tapgemm_tflop_per_step": round(tot_fl / 1e12, 3)}
-        # HBM-side bytes per launch cannot be read from inside the process: they come from the committed
-        # rocprofv3 PMC passes of this same command (tools/collect_evidence.sh -> profiles/)
-        for tname in ("r02_tapgemm_traffic.json", "r01_tapgemm_traffic.json"):
+                           # algorithmic FLOP of the products of one step (the CFG pair shares the layers ahead of the first
+                           # cross-attention, so this is a few % below the reference's 2 x forward count); a dual-W launch
+                           # executes 2x the MFMA work for its product: executed_over_algorithmic says how much
+                           "tapgemm_tflop_per_step": round(tot_fl / 1e12, 3),
+                           "executed_over_algorithmic": round(1.0 + sum(r[3] for r in recs if str(r[4][5]).endswith("+dw")) / max(tot_fl, 1.0), 3),
+                           "measured_in_this_run": True}
+        # HBM-side bytes per launch cannot be read from inside the process: they come from committed rocprofv3 PMC
+        # passes of this command (tools/collect_evidence.sh -> profiles/) and are labelled as such
+        for tname in ("r03_tapgemm_traffic.json", "r02_tapgemm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
+                if tj.get("precision", "fast") != args.precision or tj.get("dtype", "fp16") != args.dtype:
+                    continue
                 res["roofline"]["traffic"] = round(tj["hbm_bytes_per_launch"])
-                res["roofline"]["traffic_unit"] = f"bytes per launch (2*FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc, profiles/{tname})"
-                if "mfma_busy_frac" in tj:
-                    res["roofline"]["mfma_busy_frac"] = tj["mfma_busy_frac"]
+                res["roofline"]["committed"] = {
+                    "source": f"profiles/{tname} (rocprofv3 --pmc passes of this command on an earlier box; NOT measured in this run)",
+                    "traffic_unit": "bytes per launch (2*FETCH_SIZE + WRITE_SIZE)",
+                    "hbm_bytes_per_launch": round(tj["hbm_bytes_per_launch"]),
+                    "algorithmic_bytes_per_launch": tj.get("algorithmic_bytes_per_launch"),
+                    "mfma_busy_frac": tj.get("mfma_busy_frac")}
                 break
         # the HBM-bound kernel classes of the same pass, against chip peak (north_star: "HBM GB/s ... against chip peak")
         hk = {}
@@ -369,7 +493,7 @@ def main():
         from vgen_amd.vae import AutoencoderKL
         fh, fw = (int(v) for v in args.vae_size.split("x"))
         with torch.device(dev):
-            vae = AutoencoderKL(ddconfig=VAE_SD, embed_dim=4, compute_dtype=args.dtype)
+            vae = AutoencoderKL(ddconfig=VAE_SD, embed_dim=4, compute_dtype=args.dtype, precision=args.precision)
         vae.eval()
         randomize_(vae, 1)
         z = torch.randn(2, 4, fh // 8, fw // 8, device=dev) / 0.18215 * 0.2
@@ -382,7 +506,8 @@ def main():
             vae.decode(z)
         torch.cuda.synchronize()
         fps = 2 * nrep / (time.perf_counter() - t1)
-        res["vae"] = {"decode_frames_per_sec": round(fps, 2), "frame": args.vae_size, "decoder_bs": 2}
+        res["vae"] = {"decode_frames_per_sec": round(fps, 2), "frame": args.vae_size, "decoder_bs": 2,
+                      "precision": args.precision}
         if args.vae_size == "256x448":
             res["vae"]["tflops_per_s"] = round(fps * VAE_DEC_TFLOP, 2)
         if not args.no_e2e and world == 1 and part is None and args.config == "t2v":
@@ -402,29 +527,66 @@ def main():
                           "frames_per_sec": round(F / (t3 - t1), 3), "video_shape": list(vid.shape)}
         del vae
 
-    # ---- CPU baseline: the oracle on host cores, bounded sample -------------------------------------------
+    # ---- the single-pass modes, same two measurements (timed steps + parity), after the headline -------------------
+    if rank == 0 and world == 1 and part is None and args.config == "t2v" and args.variants:
+        res["variants"] = {}
+        del model, timer, sess
+        diff.sessions.clear()
+        gc.collect()
+        torch.cuda.empty_cache()
+        for v in [s for s in args.variants.split(",") if s]:
+            vdt, vpr = v.split("/")
+            if (vdt, vpr) == (args.dtype, args.precision):
+                continue
+            vm = build_model("t2v", dev, vdt, vpr, state_dict=sd)
+            drop_masters(vm, dev)
+            vd = DiffusionDDIM(**DDIM)
+            vd.rng_parity = False
+            vt = StepTimer(vd, vm, xt0, mkw, guide, dev, P)
+            k = min(args.steps, 10)
+            vdt_s, vx = vt.run(k, min(args.warmup, 2))
+            ent = {"value": round(k / vdt_s, 4), "unit": "steps/s", "ms_per_step": round(1e3 * vdt_s / k, 3), "steps": k,
+                   "dtype": vdt, "precision": vpr, "finite": bool(torch.isfinite(vx).all())}
+            if not args.no_parity:
+                e = golden_parity(vm, gold, dev)
+                ent.update(unet_rel_l2=e, within_tolerance=bool(e <= TOLERANCE))
+            res["variants"][v] = ent
+            del vm, vd, vt, vx
+            gc.collect()
+            torch.cuda.empty_cache()
+
+    # ---- CPU baseline on the host cores, bounded sample ----------------------------------------------------------
     # Sample = ONE full forward of the full-size UNetSD_T2VBase (1411 M params) on the whole 16-frame latent
-    # [1,4,16,32,56] — half a CFG step, ~15-20 s on 32 threads; a step is two such forwards.  (r01 timed a 4-frame
-    # latent and scaled by 4: the 5-D GroupNorm / temporal attention do not scale exactly with F.)  32 threads: more
-    # made the oracle slower on the 256-core host (363 s per forward with 256 threads in an earlier run).
+    # [1,4,16,32,56] — half a CFG step, ~15-20 s on 32 threads; a step is two such forwards.  32 threads: more made
+    # the fp32 torch forward slower on the 256-core host (363 s per forward with 256 threads in an earlier run).
+    # With the reference tree present (the build container) the forward is the REFERENCE's own UNetSD_T2VBase through
+    # oracle/ref_import.py (kind "reference"); on the GPU box, which has no /root/reference, the port (oracle/torch_ref.py).
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.config == "t2v":
-        from oracle import torch_ref
-        gold = torch.load(os.path.join(ROOT, "tests", "golden", "unet_t2v_full.pt"), map_location="cpu",
-                          weights_only=False)
-        sd = torch_ref.synth_state_dict(gold["shapes"], seed=0)
+        from oracle import ref_import, torch_ref
         cores = min(os.cpu_count() or 1, 32)
         torch.set_num_threads(cores)
         gen = torch.Generator("cpu").manual_seed(8888)
         x = torch.randn(1, 4, 16, 32, 56, generator=gen)
         yy = torch.randn(1, 77, 1024, generator=gen)
-        with torch.no_grad():
-            t1 = time.perf_counter()
-            torch_ref.unet_forward(sd, x, torch.tensor([981]), yy, 320)
-            fwd_s = time.perf_counter() - t1
-        res["cpu_baseline"] = {"value": round(1.0 / (2 * fwd_s), 5), "unit": "steps/s", "cores": cores,
-                               "kind": "port",
-                               "sample": "oracle (oracle/torch_ref.py, fp32) full-size UNet, one forward of the 16-frame "
-                                         f"latent [1,4,16,32,56]: {fwd_s:.1f} s; a CFG step is two forwards"}
+        tt = torch.tensor([981])
+        if ref_import.available():
+            R = ref_import.load()
+            rm = R["MODEL"].build(dict(type="UNetSD_T2VBase", **gold["cfg"])).eval()
+            rm.load_state_dict(sd, strict=True)
+            with torch.no_grad():
+                t1 = time.perf_counter()
+                rm(x, tt, y=yy)
+                fwd_s = time.perf_counter() - t1
+            kind, what = "reference", "the reference's UNetSD_T2VBase.forward (tools/modules/unet/unet_t2v.py:210-277, fp32, via oracle/ref_import.py)"
+        else:
+            with torch.no_grad():
+                t1 = time.perf_counter()
+                torch_ref.unet_forward(sd, x, tt, yy, 320)
+                fwd_s = time.perf_counter() - t1
+            kind, what = "port", "oracle/torch_ref.py (fp32 restatement of the reference forward; /root/reference is not on this box)"
+        res["cpu_baseline"] = {"value": round(1.0 / (2 * fwd_s), 5), "unit": "steps/s", "cores": cores, "kind": kind,
+                               "sample": f"{what}: one forward of the full-size UNet on the 16-frame latent "
+                                         f"[1,4,16,32,56]: {fwd_s:.1f} s; a CFG step is two forwards"}
     if rank == 0:
         print(json.dumps(res), flush=True)
     if world > 1:

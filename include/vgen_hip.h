@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VGEN_ABI_VERSION 3
+#define VGEN_ABI_VERSION 4
 
 enum { VGEN_BF16 = 0, VGEN_F16 = 1, VGEN_F32 = 2 };
 
@@ -119,7 +119,7 @@ int vgen_layernorm(const float* x, int64_t M, int32_t d, float eps,
  * skip_connection (util.py:885,920) into the out-conv.
  *
  * Constraints: C1 % 64 == 0, C2 % 64 == 0, lda/lda2 % 8 == 0, 16-byte aligned pointers,
- * ldw % 8 == 0.  A, A2, W are `dtype` (VGEN_BF16 | VGEN_F16);
+ * ldw % 8 == 0, K = taps*C1 + C2 <= 131008.  A, A2, W are `dtype` (VGEN_BF16 | VGEN_F16);
  * accumulation is fp32 on the MFMA units.
  *
  * Epilogue, applied in fp32 in this order:
@@ -169,6 +169,12 @@ typedef struct vgen_tapgemm_args {
                       GroupNorm that consumes `out` (util.py:846,870,1663-1681) skip its statistics pass
                       (vgen_groupnorm_cs).  Needs out_dtype = F32, no GEGLU, N % 4 == 0, ldo/ldr/
                       rowbias_ld % 4 == 0; the launch is then never split along K. */
+  int32_t dualw;   /* 1: two-term weights.  W holds, for every 64-element K-tile of the contraction (in the K order
+                      above), the 64 columns of W_hi followed by the 64 columns of W_lo = round16(W - W_hi): row
+                      stride ldw >= 2 K (0 = dense 2 K).  The launch computes epi(A . (W_hi + W_lo)^T) with every A
+                      K-tile staged once — the models' precision="high" mode (packed 16-bit weights are the largest
+                      rounding in the UNet; with them as hi + lo pairs its output is within 1e-3 of the reference's
+                      fp32 forward, tools/modules/unet/unet_t2v.py:210-277).  K <= 65504.  0: W is [N, K]. */
 } vgen_tapgemm_args;
 
 /* Launches whose tile count cannot fill the 256 CUs (small M: the 4x7 / 8x14 UNet levels) are

@@ -90,9 +90,14 @@ class EmuBackend:
         dt = g.A.dtype
         assert dt in (torch.bfloat16, torch.float16) and g.W.dtype == dt
         K = g.taps * g.C1 + g.C2
-        W = g.W[: g.N, :K].float()
-        if getattr(g.W, "vgen_lo", None) is not None:     # high-precision mode: the launches compute A (W_hi + W_lo)^T
-            W = W + g.W.vgen_lo[: g.N, :K].float()
+        dw = getattr(g.W, "vgen_dw", None)
+        if dw is not None:                                # dual-W launch (vgen_tapgemm_args.dualw): A (W_hi + W_lo)^T
+            from vgen_amd.ops import dw_terms
+            assert dw.dtype == dt and dw.shape[1] == 2 * K
+            hi, lo = dw_terms(dw[: g.N])
+            W = hi.float() + lo.float()
+        else:
+            W = g.W[: g.N, :K].float()
         acc = torch.zeros((g.M, g.N), dtype=torch.float32)
         for tap, r in enumerate(self._src_rows(g)):
             a = g.A[:, : g.C1][r.clamp(min=0)].float()

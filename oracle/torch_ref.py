@@ -26,23 +26,9 @@ def synth_state_dict(shapes: dict, seed: int = 0, gain: float = 0.8) -> dict:
     """Seeded re-randomisation of EVERY parameter (the reference zero-initialises the ResBlock
     out-conv, temporal conv4, proj_out, head conv — util.py:873-875,1683-1684,351,1229,
     unet_t2v.py:208 — which would make a parity check vacuous; SURVEY.md §8c "Trap").
-    >=2-D weights ~ N(0, gain/sqrt(fan_in)), norm scales ~ 1 + 0.1 N, biases ~ 0.1 N.
-    Keys are visited in sorted order with one CPU generator, so any process that knows the
-    shapes reproduces the same tensors."""
-    g = torch.Generator("cpu").manual_seed(seed)
-    sd = {}
-    for k in sorted(shapes):
-        shp = tuple(shapes[k])
-        if len(shp) >= 2:
-            fan_in = 1
-            for s in shp[1:]:
-                fan_in *= s
-            sd[k] = torch.randn(shp, generator=g) * (gain / math.sqrt(fan_in))
-        elif k.endswith("weight"):
-            sd[k] = 1.0 + 0.1 * torch.randn(shp, generator=g)
-        else:
-            sd[k] = 0.1 * torch.randn(shp, generator=g)
-    return sd
+    The recipe lives in vgen_amd/synth.py (bench.py times the very weights the golden fixtures were made with)."""
+    from vgen_amd.synth import seeded_state_dict
+    return seeded_state_dict(shapes, seed, gain)
 
 
 def shapes_of(module) -> dict:

@@ -36,6 +36,8 @@ def _clone_spec(g, dev):
             nb = base.to(dev)
             if v._base is not None:
                 nb = torch.as_strided(nb, v.shape, v.stride(), v.storage_offset())
+            if getattr(v, "vgen_dw", None) is not None:          # two-term weight: the dual-W operand travels along
+                nb.vgen_dw = v.vgen_dw.to(dev)
             kw[k] = nb
         else:
             kw[k] = v
@@ -102,9 +104,10 @@ def case_layernorm(be, dev, dt, M, d, seed=0):
 
 
 def make_tapgemm(dt, M, N, C1, mode=L.TAP_LINEAR, C2=0, bias=True, rowbias=0, residual=False,
-                 out_dtype=torch.float32, epilogue=L.EPI_NONE, a_pad=0, w_pad=0, seed=0, **geom):
+                 out_dtype=torch.float32, epilogue=L.EPI_NONE, a_pad=0, w_pad=0, seed=0, dualw=False, **geom):
     """Build a TapGemm spec on CPU.  a_pad: extra columns in A's storage (lda > C1) to exercise
-    views; w_pad likewise for W (ldw > K)."""
+    views; w_pad likewise for W (ldw > K).  dualw: W is a two-term weight (ops.split_weight of an fp32 matrix, kept as
+    `.vgen_w32`): the launch is a dual-W one."""
     g = _g(seed)
     taps = {L.TAP_LINEAR: 1, L.TAP_CONV3X3: 9, L.TAP_TEMPORAL3: 3}[mode]
     if mode == L.TAP_CONV3X3:
@@ -115,7 +118,13 @@ def make_tapgemm(dt, M, N, C1, mode=L.TAP_LINEAR, C2=0, bias=True, rowbias=0, re
         src_rows = M
     A = (torch.randn(src_rows, C1 + a_pad, generator=g)).to(dt)[:, :C1]
     K = taps * C1 + C2
-    W = (torch.randn(N, K + w_pad, generator=g) / (K ** 0.5)).to(dt)[:, :K]
+    if dualw:
+        from vgen_amd.ops import split_weight
+        w32 = torch.randn(N, K, generator=g) / (K ** 0.5)
+        W = split_weight(w32, dt)
+        W.vgen_w32 = w32
+    else:
+        W = (torch.randn(N, K + w_pad, generator=g) / (K ** 0.5)).to(dt)[:, :K]
     spec = dict(A=A, W=W, M=M, N=N, C1=C1, mode=mode, taps=taps, out_dtype=out_dtype, epilogue=epilogue)
     spec.update(geom)
     if C2:
@@ -341,6 +350,43 @@ def tapgemm_cases(dt):
     c["cs_lin_wide_dual"] = make_tapgemm(dt, 9000, 1280, 128, colstats=True)
     c["temporal_b128"] = make_tapgemm(dt, 1 * 16 * 28, 128, 128, mode=L.TAP_TEMPORAL3, F=16, S=28)
     c["lin_154x4096x1024_textmlp"] = make_tapgemm(dt, 154, 4096, 1024)
+    return c
+
+
+def tapgemm_dw_cases(dt):
+    """Dual-W launches (vgen_tapgemm_args.dualw, the models' precision="high"): every row map, both K segments, the
+    epilogues, column statistics, split-K, N tails of the three column tiles, 128- and 256-row blocks, K of one tile."""
+    c = {}
+    c["dw_lin_300x320x320"] = make_tapgemm(dt, 300, 320, 320, dualw=True)
+    c["dw_lin_1000x256x640_res"] = make_tapgemm(dt, 1000, 256, 640, residual=True, dualw=True)
+    c["dw_lin_K64"] = make_tapgemm(dt, 700, 128, 64, dualw=True)
+    c["dw_lin_out16_nobias"] = make_tapgemm(dt, 77, 128, 1024, out_dtype=dt, bias=False, dualw=True)
+    c["dw_lin_smallN"] = make_tapgemm(dt, 500, 4, 576, dualw=True)
+    c["dw_lin_nonvec"] = make_tapgemm(dt, 130, 3, 128, residual=True, dualw=True)
+    c["dw_lin_tinyM"] = make_tapgemm(dt, 2, 1280, 320, dualw=True)
+    c["dw_lin_bigM_qkv"] = make_tapgemm(dt, 9000, 960, 320, out_dtype=dt, bias=False, dualw=True)
+    c["dw_lin_rowbias"] = make_tapgemm(dt, 384, 128, 64, rowbias=96, residual=True, dualw=True)
+    c["dw_lin_geglu"] = make_tapgemm(dt, 200, 512, 64, epilogue=L.EPI_GEGLU, out_dtype=dt, dualw=True)
+    c["dw_lin_geglu_res"] = make_tapgemm(dt, 4100, 2560, 320, epilogue=L.EPI_GEGLU, out_dtype=dt, residual=True, dualw=True)
+    c["dw_conv_s1_rowbias"] = make_tapgemm(dt, 3 * 9 * 7, 128, 64, mode=L.TAP_CONV3X3, nimg=3, Hi=9, Wi=7, Ho=9, Wo=7,
+                                           stride=1, pad_t=1, pad_l=1, ups=0, rowbias=63, dualw=True)
+    c["dw_conv_s2"] = make_tapgemm(dt, 2 * 5 * 4, 64, 128, mode=L.TAP_CONV3X3, nimg=2, Hi=10, Wi=8, Ho=5, Wo=4,
+                                   stride=2, pad_t=1, pad_l=1, ups=0, dualw=True)
+    c["dw_conv_ups_crop"] = make_tapgemm(dt, 2 * 10 * 10, 64, 64, mode=L.TAP_CONV3X3, nimg=2, Hi=6, Wi=5, Ho=10, Wo=10,
+                                         stride=1, pad_t=1, pad_l=1, ups=1, crop_t=1, dualw=True)
+    c["dw_conv_skipseg"] = make_tapgemm(dt, 2 * 6 * 6, 128, 128, mode=L.TAP_CONV3X3, nimg=2, Hi=6, Wi=6, Ho=6, Wo=6,
+                                        stride=1, pad_t=1, pad_l=1, ups=0, C2=192, dualw=True)
+    c["dw_conv_big_cs"] = make_tapgemm(dt, 4 * 32 * 56, 320, 320, mode=L.TAP_CONV3X3, nimg=4, Hi=32, Wi=56, Ho=32, Wo=56,
+                                       stride=1, pad_t=1, pad_l=1, ups=0, residual=True, colstats=True, dualw=True)
+    c["dw_conv_splitk_L3"] = make_tapgemm(dt, 16 * 4 * 7, 1280, 1280, mode=L.TAP_CONV3X3, nimg=16, Hi=4, Wi=7, Ho=4, Wo=7,
+                                          stride=1, pad_t=1, pad_l=1, ups=0, residual=True, rowbias=28 * 8, dualw=True)
+    c["dw_conv_wideK"] = make_tapgemm(dt, 2 * 8 * 14, 1280, 2560, mode=L.TAP_CONV3X3, nimg=2, Hi=8, Wi=14, Ho=8, Wo=14,
+                                      stride=1, pad_t=1, pad_l=1, ups=0, C2=2560, dualw=True)      # K = 25600: r02's bound was 32704 / 2
+    c["dw_temporal"] = make_tapgemm(dt, 2 * 5 * 24, 64, 64, mode=L.TAP_TEMPORAL3, F=5, S=24, residual=True, dualw=True)
+    c["dw_temporal_cs"] = make_tapgemm(dt, 2 * 8 * 96, 640, 640, mode=L.TAP_TEMPORAL3, F=8, S=96, residual=True,
+                                       colstats=True, dualw=True)
+    c["dw_temporal_splitk"] = make_tapgemm(dt, 2 * 4 * 28, 640, 640, mode=L.TAP_TEMPORAL3, F=4, S=28, residual=True, dualw=True)
+    c["dw_lin_splitk_out16"] = make_tapgemm(dt, 300, 256, 2048, out_dtype=dt, dualw=True)
     return c
 
 

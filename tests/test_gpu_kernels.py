@@ -49,6 +49,27 @@ def test_tapgemm(hip_backend, dtname, name):
         assert cs["finite"] and cs["rel_l2"] <= 2e-5, cs
 
 
+_TGDW = sorted(kc.tapgemm_dw_cases(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtname", ["bf16", "fp16"])
+@pytest.mark.parametrize("name", _TGDW)
+def test_tapgemm_dualw(hip_backend, dtname, name):
+    """Dual-W launches (precision="high"): vs the emulator's A . (W_hi + W_lo)^T, and — the point of the mode — vs the
+    product with the UNROUNDED fp32 weight: what is left of the weight rounding is 2^-22 (fp16) / 2^-16 (bf16)."""
+    import torch_ops_ref as tr
+    spec = kc.tapgemm_dw_cases(kc.DTS[dtname])[name]
+    res = kc.case_tapgemm(hip_backend, DEV, spec)
+    cs = res.pop("colstats", None)
+    _check(res, dtname, out_is_16=spec.out_dtype != torch.float32)
+    if cs is not None:
+        assert cs["finite"] and cs["rel_l2"] <= 2e-5, cs
+    out = hip_backend.tapgemm(kc._clone_spec(spec, DEV)).float().cpu()
+    err = kc.stats(out, tr.ref_tapgemm(spec, w32=spec.W.vgen_w32))["rel_l2"]
+    tol = kc.TOL16[dtname] if spec.out_dtype != torch.float32 else (2e-5 if dtname == "fp16" else 1.5e-4)
+    assert err <= tol, (name, err)
+
+
 @pytest.mark.parametrize("dtname", ["bf16", "fp16"])
 def test_kernels_vs_plain_torch_operators(hip_backend, dtname):
     """The HIP kernels against torch's own fp32 operators on NCHW tensors (tests/torch_ops_ref.py: F.conv2d / conv1d /

@@ -60,9 +60,10 @@ def test_every_vae_block_alone_vs_reference_golden(emu_backend):
 
 
 def test_high_precision_mode_splits_every_packed_weight(emu_backend):
-    """precision="high": the packers attach the rounding residual to every 16-bit weight operand (W_hi + W_lo == the
-    fp32 weight to ~2^-21), linear launches take it as a second K segment and tap gathers as a second launch — checked
-    on the launch stream; the tiny UNet moves from 1.5e-3 to 1.1e-3 of the reference's fp32 forward."""
+    """precision="high": the packers attach to every 16-bit weight operand its two-term form `.vgen_dw` = per 64-column
+    K-tile [W_hi | W_lo] (W_hi + W_lo == the fp32 weight to ~2^-21); every launch that finds it is ONE dual-W launch
+    (vgen_tapgemm_args.dualw) — linear, 3x3 and temporal gathers alike; the tiny UNet moves from 1.5e-3 to 1.1e-3 of
+    the reference's fp32 forward."""
     from vgen_amd import ops
     m, g, sd = _unet("fp16")
     from vgen_amd.unet import UNetSD_T2VBase
@@ -72,32 +73,47 @@ def test_high_precision_mode_splits_every_packed_weight(emu_backend):
     name = next(n for n, mod in mh.named_modules() if type(mod).__name__ == "_ResBlockP" and isinstance(mod.skip_connection, torch.nn.Conv2d))
     for w in (P[name]["conv1"][0], P[name]["conv2"][0], P[name]["tconv1"][0], P["kv_all"],
               P[next(n for n, mod in mh.named_modules() if type(mod).__name__ == "_SpatialTransformerP")]["tb"]["ff1"][0]):
-        assert w.vgen_lo.shape == w.shape and w.vgen_hilo.shape == (w.shape[0], 2 * w.shape[1])
-        assert getattr(w.vgen_plain, "vgen_lo", None) is None
+        assert w.vgen_dw.shape == (w.shape[0], 2 * w.shape[1]) and w.vgen_dw.dtype == w.dtype
+        hi, lo = ops.dw_terms(w.vgen_dw)
+        assert torch.equal(hi, w)
     rb = mh.get_submodule(name)
     full = torch.cat([rb.out_layers[3].weight.detach().permute(0, 2, 3, 1).reshape(rb.cout, -1), rb.skip_connection.weight.detach().reshape(rb.cout, -1)], 1)
     w = P[name]["conv2"][0]
-    assert float(((w.float() + w.vgen_lo.float()) - full).abs().max() / full.abs().max()) < 2e-6
+    hi, lo = ops.dw_terms(w.vgen_dw)
+    assert float(((hi.float() + lo.float()) - full).abs().max() / full.abs().max()) < 2e-6
     e_fast = rel_l2(m(g["x"], g["t"], y=g["y"]), g["out"])
     e_high = rel_l2(mh(g["x"], g["t"], y=g["y"]), g["out"])
     assert e_high < 0.8 * e_fast and e_high < 1.2e-3, (e_fast, e_high)
-    # the decomposition itself, launch by launch, on a recording backend
+    # every tap-GEMM of the high-precision forward is one launch on a two-term weight (the stem's own [hi | lo | hi]
+    # split and the cross-attention K/V aside, nothing runs on a plain 16-bit weight)
     seen = []
     be = ops.backend()
     orig = be.tapgemm
-    be.tapgemm = lambda spec: (seen.append((spec.mode, spec.C2, getattr(spec.W, "vgen_lo", None) is not None)), orig(spec))[1]
+    be.tapgemm = lambda spec: (seen.append((spec.mode, getattr(spec.W, "vgen_dw", None) is not None)), orig(spec))[1]
     try:
-        x = torch.randn(64, 128).half()
-        w = ops.split_weight(torch.randn(64, 128), torch.float16)
-        ops._tapgemm_weight_split(be, ops.TapGemm(A=x, W=w, M=64, N=64, C1=128))
-        assert seen == [(0, 128, False)]                                      # one launch, K doubled
-        seen.clear()
-        wt = ops.split_weight(torch.randn(64, 3 * 64), torch.float16)
-        xt = torch.randn(2 * 4 * 8, 64).half()
-        ops._tapgemm_weight_split(be, ops.TapGemm(A=xt, W=wt, M=64, N=64, C1=64, mode=2, taps=3, F=4, S=8, bias=torch.randn(64)))
-        assert [s[0] for s in seen] == [2, 2] and not any(s[2] for s in seen)   # two gathers: W_hi, then W_lo on top
+        mh(g["x"], g["t"], y=g["y"])
     finally:
         del be.tapgemm
+    assert {md for md, _ in seen} == {0, 1, 2}
+    plain = [md for md, dw in seen if not dw]
+    assert plain == [0], plain                                      # the stem conv (its own 3-segment split)
+
+
+def test_dual_w_launch_semantics_vs_fp32_weights(emu_backend):
+    """The dual-W cases of the GPU suite on the emulator: A . (W_hi + W_lo)^T reproduces the product with the unrounded
+    fp32 weight to the residual of the split (2^-22 fp16 / 2^-17 bf16), through plain-torch operators on NCHW tensors."""
+    import kernel_cases as kc
+    import torch_ops_ref as tr
+    for dtname, tol in (("fp16", 3e-6), ("bf16", 6e-5)):
+        dt = kc.DTS[dtname]
+        for name, spec in kc.tapgemm_dw_cases(dt).items():
+            if spec.M * spec.N * (spec.taps * spec.C1 + spec.C2) > 3e10:
+                continue                                            # the big ones run on the GPU
+            out = kc.EMU.tapgemm(spec).float()
+            ref = tr.ref_tapgemm(spec, w32=spec.W.vgen_w32)
+            err = kc.stats(out, ref)["rel_l2"]
+            lim = kc.TOL16[dtname] if spec.out_dtype != torch.float32 else tol
+            assert err <= lim, (dtname, name, err)
 
 
 def test_unet_other_shapes_vs_oracle(emu_backend):
@@ -198,6 +214,16 @@ def test_ancestral_sampler_and_q_helpers_bit_exact_vs_reference_golden(emu_backe
     assert torch.equal(d.q_sample(g["x0"], t), g["q_sample"])
     with pytest.raises(NotImplementedError):
         d.p_sample(g["noise"], t, dummy_model, g["kw"], guide_scale=9.0, condition_fn=lambda *a, **k: 0)
+    # the reference's default var_type is 'learned_range' (diffusion_ddim.py:34): construction and DDIM sampling, which
+    # never reads it, work as in the reference; only the ancestral path that needs the learned variance says no
+    cfg = {k: v for k, v in g["cfg"].items() if k != "var_type"}
+    dl = DiffusionDDIM(**cfg)
+    assert dl.var_type == "learned_range"
+    torch.manual_seed(5)
+    assert same(dl.ddim_sample(g["noise"].clone(), t, dummy_model, g["kw"], guide_scale=9.0, ddim_timesteps=50, eta=0.7),
+                g["ddim_eta"])
+    with pytest.raises(NotImplementedError):
+        dl.p_mean_variance(g["noise"], t, dummy_model, g["kw"], guide_scale=9.0)
 
 
 def test_ddim_call_pattern_and_rng_parity(emu_backend):

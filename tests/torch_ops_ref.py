@@ -23,11 +23,12 @@ def ref_layernorm(x, gamma, beta, eps):
     return Fn.layer_norm(x.float(), (x.shape[1],), gamma, beta, eps)
 
 
-def ref_tapgemm(g):
-    """fp32 result of a TapGemm spec ([M, n_out]) from NCHW convolutions."""
+def ref_tapgemm(g, w32=None):
+    """fp32 result of a TapGemm spec ([M, n_out]) from NCHW convolutions.  w32: use this fp32 weight instead of the
+    16-bit operand (dual-W launches are checked against the unrounded weight)."""
     C1, N = g.C1, g.N
     A = g.A[:, :C1].float()
-    W = g.W[:N].float()
+    W = g.W[:N].float() if w32 is None else w32[:N].float()
     if g.mode == L.TAP_LINEAR:
         acc = Fn.linear(A[: g.M], W[:, :C1])
     elif g.mode == L.TAP_CONV3X3:

@@ -125,8 +125,8 @@ class KnobEmu(EmuBackend):
     def timestep_embedding(self, t, dim, dt):
         return self.r(super().timestep_embedding(t, dim, torch.float32), "temb")
 
-    def im2col3x3_small(self, src, nimg, Fi, Cin, H, W, strides, Kpad, dt):
-        return self.r(super().im2col3x3_small(src, nimg, Fi, Cin, H, W, strides, Kpad, torch.float32), "stem")
+    def im2col3x3_small(self, src, nimg, Fi, Cin, H, W, strides, Kpad, dt, split=False):
+        return self.r(super().im2col3x3_small(src, nimg, Fi, Cin, H, W, strides, Kpad, torch.float32, split=split), "stem")
 
 
 def tag_roles(model):
@@ -241,11 +241,14 @@ def main():
         return e
 
     if args.by_module:
-        go("all", CATS)
+        cats = [c for c in args.set.split(",") if c] if args.set else CATS      # --by-module --set w_lin,w_conv: weights only
+        go("all", cats)
         names = scope_modules(m, KnobEmu(dt, []))
-        go("module:glue (stem/head/down/up/emb)", CATS, ["glue"])
+        go("module:glue (stem/head/down/up/emb)", cats, ["glue"])
         for n in names:
-            go("module:" + n, CATS, [n])
+            go("module:" + n, cats, [n])
+            if args.out:
+                json.dump(res, open(args.out, "w"), indent=1)
     elif args.set is not None:
         go("set:" + args.set, [c for c in args.set.split(",") if c])
     else:

@@ -37,17 +37,26 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    os.makedirs(OBJ, exist_ok=True)
+TUNING_LIB = os.path.join(HERE, "libvgen_hip_tuning.so")
+
+
+def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> str:
+    """tuning=True builds libvgen_hip_tuning.so with -DVGEN_TUNING: the tap-GEMM's phase-ablation switches and plan
+    overrides (environment variables read per launch) exist only there — tools/ select it with VGEN_HIP_LIB; the product
+    library cannot be told to skip work."""
+    obj_dir = OBJ + ("_tuning" if tuning else "")
+    lib_path = TUNING_LIB if tuning else LIB
+    flags = FLAGS + (["-DVGEN_TUNING"] if tuning else [])
+    os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     jobs = []
     objs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+        o = os.path.join(obj_dir, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + HEADERS):
-            jobs.append([hipcc] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([hipcc] + flags + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -60,10 +69,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if jobs:
         with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 2)) as ex:
             list(ex.map(run, jobs))
-    if force or jobs or _stale(LIB, objs):
-        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    if force or jobs or _stale(lib_path, objs):
+        run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib_path] + objs)
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True))
+    print(build(force="--force" in sys.argv, verbose=True, tuning="--tuning" in sys.argv))

@@ -61,10 +61,12 @@ struct RowState {
 constexpr int INVALID = -(1 << 24);
 
 // Source of padding / out-of-range rows: a zero REGION long enough for a pointer to walk a whole K extent through it
-// (K * 2 bytes <= 64 KiB - 128, checked on the host), so every DMA source pointer advances by the same ROW_BYTES
-// per K-tile whether its row is live or not — no per-piece increment registers (7 VGPRs on the dual shape, which
-// sat at 256 VGPRs with 3 spills).
-constexpr int ZERO_BYTES = 65536;
+// (K * 2 bytes — twice that on the W side of a dual-W launch — <= 256 KiB - 128, checked on the host), so every DMA
+// source pointer advances by the same ROW_BYTES per K-tile whether its row is live or not — no per-piece increment
+// registers (7 VGPRs on the dual shape, which sat at 256 VGPRs with 3 spills).  256 KiB: K <= 131008 for a plain
+// launch, <= 65504 with dual-W — the VAE's P.V product over a 90 x 160 latent (K = 14400) and the widest decoder
+// conv of the UNet (K = 9 * 2560, dual-W) fit with room (r02's 64 KiB bound did not: ADVICE r02).
+constexpr int ZERO_BYTES = 262144;
 __device__ __attribute__((aligned(128))) unsigned char g_zeros[ZERO_BYTES];
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
@@ -95,10 +97,28 @@ __device__ __forceinline__ int swz_key(int row) {
   }
 }
 
-template <typename T, int BM, int BN, int BK, int WM, int WN, int STAGES, bool PP>
+// Phase-ablation switches (skip the K loop / the stores / force tile (0,0)) exist only in the TUNING build of this
+// file (-DVGEN_TUNING, tools/ build a separate libvgen_hip_tuning.so): in the product library `ablate` is the
+// constant 0, the branches below fold away and no environment variable can make a launch skip its work.
+#ifdef VGEN_TUNING
+#define VGEN_ABLATE_ARG(x) (x)
+#else
+#define VGEN_ABLATE_ARG(x) 0
+#endif
+
+// DW ("dual-W", vgen_tapgemm_args.dualw): the weight operand carries, for every 64-element K-tile, the tile of W_hi
+// followed by the tile of W_lo = round16(W - W_hi); the launch computes A . (W_hi + W_lo)^T — the high-precision mode
+// of the models — with every A K-tile staged and read from LDS ONCE: an even K-step is an ordinary ping-pong step
+// (A + W_hi), the odd step that follows stages and reads only the W_lo tile and multiplies it with the A fragments
+// still sitting in registers.  r02 ran this product as a K-doubled launch ([A | A] x [W_hi | W_lo], every A tile
+// gathered, DMA'd and ds_read twice) or, for tap gathers, as two launches through an fp32 temporary.
+template <typename T, int BM, int BN, int BK, int WM, int WN, int STAGES, bool PP, bool DW>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_kernel(
-    const vgen_tapgemm_args p, const int splitk, float* __restrict__ ws, const int ablate) {
+    const vgen_tapgemm_args p, const int splitk, float* __restrict__ ws, const int ablate_arg) {
   static_assert(!PP || (WM * WN == 8 && STAGES == 3), "ping-pong needs 8 waves and a 3-stage ring");
+  static_assert(!DW || (PP && BK == 64), "dual-W K-steps are built on the ping-pong schedule, 64-element K-tiles");
+  const int ablate = VGEN_ABLATE_ARG(ablate_arg);
+  constexpr int WPA = DW ? 2 : 1;               // W K-tiles per A K-tile
   constexpr int NT = WM * WN * 64;              // threads
   constexpr int ROW_BYTES = BK * 2;             // bytes per LDS tile row
   constexpr int CPR = ROW_BYTES / 16;           // 16-byte chunks per row
@@ -143,7 +163,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   const uint16_t* __restrict__ A = (const uint16_t*)p.A;
   const uint16_t* __restrict__ A2 = (const uint16_t*)p.A2;
   const uint16_t* __restrict__ W = (const uint16_t*)p.W;
-  const int64_t ldw = p.ldw ? p.ldw : (int64_t)p.taps * p.C1 + p.C2;
+  const int64_t ldw = p.ldw ? p.ldw : ((int64_t)p.taps * p.C1 + p.C2) * WPA;
 
   // ---- per-thread DMA assignment: LDS chunk position ld_c of tile rows ld_r + RPP*i -----------
   const int ld_c = tid % CPR;
@@ -180,7 +200,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
 
   const int cpt1 = p.C1 / BK;           // K-tiles per tap of segment 1
   const int T1 = p.taps * cpt1;
-  const int KT = T1 + p.C2 / BK;
+  const int KT = T1 + p.C2 / BK;        // K-tiles of the A side (the W side has WPA per A tile)
   // this block's K-tile range (split-K: blockIdx.y)
   const int split = blockIdx.y;
   const int kt_begin = (int)(((int64_t)KT * split) / splitk);
@@ -189,7 +209,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   // stores — the phase decomposition of a launch (profiles/r02_tapgemm_ablation.json); bit 2 takes the 8-byte
   // store path for 16-bit outputs (A/B of the paired 16-byte stores); bit 3 see lm0 above
   // (profiles/r02_tapgemm_l2_ablation.json: the K loop is not fabric-bound)
-  const int nk = (ablate & 1) ? 0 : kt_end - kt_begin;
+  const int nk = (ablate & 1) ? 0 : (kt_end - kt_begin) * WPA;   // K-steps = W K-tiles
 
   // ---- incremental per-lane DMA source pointers ---------------------------------------------
   // pc[j] = source of piece j for the NEXT K-tile to issue; consecutive K-tiles inside one tap /
@@ -250,9 +270,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   for (int i = 0; i < NP - RA; ++i) {
     const int n = ln0 + ld_r + RPP * i;
     const bool ok = n < p.N;
-    pc[RA + i] = (ok ? (const char*)(W + (int64_t)n * ldw + (int64_t)kt_begin * BK) : zline) + src_cb;
+    pc[RA + i] = (ok ? (const char*)(W + (int64_t)n * ldw + (int64_t)kt_begin * WPA * BK) : zline) + src_cb;
   }
-  auto advance = [&]() __attribute__((always_inline)) {   // pointers -> next K-tile
+  auto advance_a = [&]() __attribute__((always_inline)) {   // A pointers -> next A K-tile
     ++kt_next;
     if (--left == 0) {
       if (kt_next < KT) gather_a(kt_next);
@@ -260,8 +280,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
 #pragma unroll
       for (int i = 0; i < RA; ++i) pc[i] += ROW_BYTES;
     }
+  };
+  auto advance_w = [&]() __attribute__((always_inline)) {   // W pointers -> next W K-tile
 #pragma unroll
     for (int i = RA; i < NP; ++i) pc[i] += ROW_BYTES;
+  };
+  auto advance = [&]() __attribute__((always_inline)) {
+    advance_a();
+    advance_w();
   };
   // LDS destination (wave-uniform) of piece j in `stage`
   auto piece_dst = [&](int stage, int j) __attribute__((always_inline)) -> unsigned char* {
@@ -273,6 +299,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
     for (int j = 0; j < LPT; ++j) glds16(pc[j], piece_dst(stage, j));
     if (RBT > 0 && w_tail) glds16(pc[NP - 1], piece_dst(stage, NP - 1));
     advance();
+  };
+  auto load_tile_w = [&](int stage) __attribute__((always_inline)) {   // dual-W odd K-tile: the W_lo pieces only
+#pragma unroll
+    for (int j = RA; j < LPT; ++j) glds16(pc[j], piece_dst(stage, j));
+    if (RBT > 0 && w_tail) glds16(pc[NP - 1], piece_dst(stage, NP - 1));
+    advance_w();
   };
 
   // Accumulators start from the fp32 RESIDUAL tile instead of zero: the residual loads (one HBM / MALL round trip
@@ -379,8 +411,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   //   hazards: DMA(t+2) overwrites the stage of tile t-1, last read in R(t-1) of both groups, i.e.
   //   before the barrier that precedes the earlier group's R(t);  tile t+1 is complete once every
   //   wave passed the vmcnt at the end of its R(t), which for both groups is before any R(t+1).
-  auto read_phase = [&](int stage, auto prefetch_tag, int stage_pf) __attribute__((always_inline)) {
+  // `odd_tag` (dual-W only): the odd K-step of a pair reads the W_lo fragments and issues the W pieces of the next odd
+  // tile — the A fragments of the even step stay in their registers, the A region of the odd stages stays unused.
+  auto read_phase = [&](int stage, auto prefetch_tag, int stage_pf, auto odd_tag) __attribute__((always_inline)) {
     constexpr bool prefetch = decltype(prefetch_tag)::value;
+    constexpr bool odd = decltype(odd_tag)::value;
     static_assert(!PP || MH == 1, "ping-pong keeps a whole K-tile of fragments in registers");
     // fragment reads and DMA issues interleaved: a DMA instruction parks the wave on the CU's texture-address path
     // while the LDS serves the reads issued just before it (issued as two blocks, reads then DMAs, the two phases
@@ -389,12 +424,15 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
     // 2 or 3 reads per DMA, DMA leading or trailing its group: all within 0.2 %.
     const unsigned char* bw = smem + stage * STAGE_BYTES + BM * ROW_BYTES + wn * WTN * ROW_BYTES + rd_row;
     const unsigned char* bx = smem + stage * STAGE_BYTES + (wm * WTM) * ROW_BYTES + rd_row;
-    constexpr int NR = KS * (NF + MF);                 // fragment reads per wave and K-tile
-    constexpr int EVERY = (NR + NP) / (NP + 1) > 0 ? (NR + NP) / (NP + 1) : 1;   // reads between two DMA issues (3)
-    int piece = 0;
+    constexpr int P0 = odd ? RA : 0;                   // first DMA piece this phase issues
+    constexpr int NPI = NP - P0;
+    constexpr int NRF = odd ? NF : NF + MF;            // fragment reads per k-step
+    constexpr int NR = KS * NRF;                       // fragment reads per wave and K-tile
+    constexpr int EVERY = (NR + NPI) / (NPI + 1) > 0 ? (NR + NPI) / (NPI + 1) : 1;   // reads between two DMA issues (3)
+    int piece = P0;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-      const int ks = r / (NF + MF), q = r % (NF + MF);
+      const int ks = r / NRF, q = r % NRF;
       const int co = ((ks * 4 + lq) ^ sw) << 4;
       if (q < NF) wf[ks][q] = *(const u32x4*)(bw + q * 16 * ROW_BYTES + co);
       else xf[ks][q - NF] = *(const u32x4*)(bx + (q - NF) * 16 * ROW_BYTES + co);
@@ -430,8 +468,15 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   // made hipcc give every accumulator a second register for the join (2 x 128 on the dual shape =
   // spills to scratch inside the K loop).
   constexpr int AHEAD = STAGES - 1;
-  for (int i = 0; i < AHEAD; ++i)
-    if (nk > i) load_tile(i);
+  if constexpr (DW) {
+    if (nk > 0) {
+      load_tile(0);
+      load_tile_w(1);
+    }
+  } else {
+    for (int i = 0; i < AHEAD; ++i)
+      if (nk > i) load_tile(i);
+  }
   int st_c = 0, st_l = AHEAD;   // stage to compute / stage to load into
   const int nk_main = nk > AHEAD ? nk - AHEAD : 0;
   auto rotate = [&]() __attribute__((always_inline)) {
@@ -442,7 +487,51 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
     if (w_tail) wait_vmcnt<LPT + 1>();
     else wait_vmcnt<LPT>();
   };
-  if constexpr (PP) {
+  auto wait_next_w = [&]() __attribute__((always_inline)) {   // ... when the newest tile is a dual-W odd one (W pieces only)
+    if (w_tail) wait_vmcnt<LPT - RA + 1>();
+    else wait_vmcnt<LPT - RA>();
+  };
+  if constexpr (PP && DW) {
+    // K-steps come in (even, odd) pairs: nk is even.  Tile t+2 has the parity of tile t, so an even step issues (and
+    // leaves in flight) a full tile, an odd step the W pieces only; each waits for the tile of the OTHER parity.
+    const bool follower = wave >= 4;
+    if (nk > 0) {
+      wait_next_w();                                    // tile 0 landed, tile 1 (W_lo of the first pair) may fly
+      __builtin_amdgcn_s_barrier();
+      if (follower) __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      auto dw_step = [&](auto prefetch_tag, auto odd_tag) __attribute__((always_inline)) {
+        constexpr bool pf = decltype(prefetch_tag)::value;
+        constexpr bool odd = decltype(odd_tag)::value;
+        read_phase(st_c, prefetch_tag, st_l, odd_tag);
+        if constexpr (pf) {
+          if constexpr (odd) wait_next_w();             // tile it+1 (even: full) landed, it+2 (odd: W only) may fly
+          else wait_next();                             // tile it+1 (odd) landed, it+2 (even: full) may fly
+        } else {
+          wait_vmcnt<0>();
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_phase();
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (pf) {
+          if constexpr (!odd) advance_a();
+          advance_w();
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        rotate();
+      };
+      for (int it = 0; it + 2 < nk; it += 2) {
+        dw_step(std::true_type{}, std::false_type{});
+        dw_step(std::true_type{}, std::true_type{});
+      }
+      dw_step(std::false_type{}, std::false_type{});
+      dw_step(std::false_type{}, std::true_type{});
+      if (!follower) __builtin_amdgcn_s_barrier();
+    }
+  } else if constexpr (PP) {
     const bool follower = wave >= 4;
     if (nk > 1) wait_next();
     else wait_vmcnt<0>();
@@ -450,7 +539,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
     if (follower) __builtin_amdgcn_s_barrier();         // run one phase behind
     asm volatile("" ::: "memory");
     auto pp_step = [&](auto prefetch_tag, bool more) __attribute__((always_inline)) {
-      read_phase(st_c, prefetch_tag, st_l);
+      read_phase(st_c, prefetch_tag, st_l, std::false_type{});
       // tile it+1 (issued one iteration ago) must have landed before the NEXT read phase of anyone
       if (more) wait_next();
       else wait_vmcnt<0>();
@@ -772,10 +861,12 @@ struct Plan {
   int splitk;
 };
 
+#ifdef VGEN_TUNING
 int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
 }
+#endif
 
 // Measured plans for the launches of the reference's t2v UNet at its benchmark shape (tools/autotune_gemm.py
 // times every (shape, BN, split-K) candidate per distinct launch signature on the GPU and writes this table):
@@ -804,8 +895,12 @@ Plan make_plan(const vgen_tapgemm_args& a) {
   if (a.N % 128 == 0) cands[nc++] = 128;
   if (a.N % 160 == 0 && !geglu) cands[nc++] = 160;
   if (nc == 0) cands[nc++] = 64;
-  // tuning switches (not part of the ABI): VGEN_TAPGEMM_SHAPE = 0 (pp) / 1 (dual) / 2 (pp128) forces a shape
+  // tuning build only (not part of the ABI): VGEN_TAPGEMM_SHAPE = 0 (pp) / 1 (dual) / 2 (pp128) forces a shape
+#ifdef VGEN_TUNING
   static const int force_shape = env_int("VGEN_TAPGEMM_SHAPE", -1);
+#else
+  constexpr int force_shape = -1;
+#endif
   const int smax = (vec && a.colstats == nullptr) ? (KT / 4 < 32 ? KT / 4 : 32) : 1;
   // HBM time of the epilogue traffic (output + fp32 residual), not hidden behind MFMAs when every CU
   // runs one block in the same phase ("pp"); about half hidden with two independent blocks per CU
@@ -816,16 +911,20 @@ Plan make_plan(const vgen_tapgemm_args& a) {
     bool ok = bn == 64 && a.N % 64 == 0 && (!geglu || a.N % 64 == 0);
     for (int c = 0; c < nc; ++c) ok |= cands[c] == bn;
     return ok && shape >= SHAPE_PP && shape <= SHAPE_PP128 && sk >= 1 && sk <= (smax < 1 ? 1 : smax) &&
-           !(a.colstats && shape == SHAPE_PP128);
+           !(a.colstats && shape == SHAPE_PP128) && !(a.dualw && shape == SHAPE_DUAL);
   };
-  // tuning switches (not part of the ABI): VGEN_TAPGEMM_PLAN="shape,bn,splitk" forces one plan (read on every
-  // call: the autotuner flips it between launches); VGEN_TAPGEMM_TABLE=0 ignores the measured table
+#ifdef VGEN_TUNING
+  // tuning build only: VGEN_TAPGEMM_PLAN="shape,bn,splitk" forces one plan (read on every call: the autotuner flips
+  // it between launches); VGEN_TAPGEMM_TABLE=0 ignores the measured table
   if (const char* fp = getenv("VGEN_TAPGEMM_PLAN")) {
     int sh = -1, bn = 0, sk = 0;
     if (sscanf(fp, "%d,%d,%d", &sh, &bn, &sk) == 3 && legal(sh, bn, sk)) return Plan{sh, bn, sk};
   }
   static const bool use_table = env_int("VGEN_TAPGEMM_TABLE", 1) != 0;
-  if (use_table && force_shape < 0) {
+#else
+  constexpr bool use_table = true;
+#endif
+  if (use_table && force_shape < 0 && !a.dualw) {
     const int flags = (a.residual ? 1 : 0) | (a.rowbias ? 2 : 0) | (a.colstats ? 4 : 0);
     const PlanEntry* tab = g_nplans >= 0 ? g_plans : kPlans;
     const int ntab = g_nplans >= 0 ? g_nplans : (int)(sizeof(kPlans) / sizeof(kPlans[0]));
@@ -842,6 +941,7 @@ Plan make_plan(const vgen_tapgemm_args& a) {
   for (int shape = SHAPE_PP; shape <= SHAPE_PP128; ++shape) {
     if (force_shape >= 0 && shape != force_shape && !(a.colstats && force_shape == SHAPE_PP128)) continue;
     if (a.colstats && shape == SHAPE_PP128) continue;   // 32-row wave tiles: a slab would span two waves
+    if (a.dualw && shape == SHAPE_DUAL) continue;       // dual-W K-steps exist on the ping-pong shapes only
     const int bm = shape == SHAPE_PP128 ? 128 : 256;
     const int64_t tiles_m = (a.M + bm - 1) / bm;
     for (int c = 0; c < nc; ++c) {
@@ -856,11 +956,13 @@ Plan make_plan(const vgen_tapgemm_args& a) {
       for (int s = 1; s <= (smax < 1 ? 1 : smax); ++s) {
         const int64_t blocks = tiles * s;
         const int kts = (KT + s - 1) / s;
+        // a dual-W pair = an ordinary K-step + an odd step that reads 10 of 18 fragments and issues 3 of 7 DMA pieces
+        const double dwf = a.dualw ? 1.6 : 1.0;
         double cost;
         if (shape == SHAPE_PP) {
-          cost = (double)((blocks + 255) / 256) * (kts * t_pp[bi] + 8.0) + epi_us;
+          cost = (double)((blocks + 255) / 256) * (kts * dwf * t_pp[bi] + 8.0) + epi_us;
         } else if (shape == SHAPE_PP128) {
-          cost = (double)((blocks + 255) / 256) * (kts * t_p128[bi] + 6.0) + epi_us;
+          cost = (double)((blocks + 255) / 256) * (kts * dwf * t_p128[bi] + 6.0) + epi_us;
         } else if (blocks <= 256) {
           cost = kts * t_d1[bi] + 10.0 + epi_us;
         } else {
@@ -877,12 +979,12 @@ Plan make_plan(const vgen_tapgemm_args& a) {
   return best;
 }
 
-template <typename T, int BM, int BN, int BK, int WM, int WN, int STAGES, bool PP>
+template <typename T, int BM, int BN, int BK, int WM, int WN, int STAGES, bool PP, bool DW = false>
 int launch(const vgen_tapgemm_args& a, int splitk, hipStream_t stream) {
   constexpr size_t lds = (size_t)STAGES * (BM + BN) * BK * 2;
   static bool attr_done = false;
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute((const void*)tapgemm_kernel<T, BM, BN, BK, WM, WN, STAGES, PP>,
+    hipError_t e = hipFuncSetAttribute((const void*)tapgemm_kernel<T, BM, BN, BK, WM, WN, STAGES, PP, DW>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       vgen_set_error("tapgemm: hipFuncSetAttribute(%zu B LDS) failed: %s", lds,
@@ -901,9 +1003,14 @@ int launch(const vgen_tapgemm_args& a, int splitk, hipStream_t stream) {
   }
   if (splitk > 1 && (a.ws == nullptr || a.ws_bytes < (size_t)splitk * a.M * a.N * sizeof(float)))
     splitk = 1;   // caller did not provide the workspace: still correct, just fewer blocks
+#ifdef VGEN_TUNING
   const char* ab = getenv("VGEN_TAPGEMM_ABLATE");
-  hipLaunchKernelGGL((tapgemm_kernel<T, BM, BN, BK, WM, WN, STAGES, PP>), dim3((unsigned)grid, (unsigned)splitk),
-                     dim3(WM * WN * 64), lds, stream, a, splitk, (float*)a.ws, ab ? atoi(ab) : 0);
+  const int ablate = ab ? atoi(ab) : 0;
+#else
+  const int ablate = 0;
+#endif
+  hipLaunchKernelGGL((tapgemm_kernel<T, BM, BN, BK, WM, WN, STAGES, PP, DW>), dim3((unsigned)grid, (unsigned)splitk),
+                     dim3(WM * WN * 64), lds, stream, a, splitk, (float*)a.ws, ablate);
   int rc = vgen_check_launch("tapgemm");
   if (rc || splitk == 1) return rc;
   const int n_out = a.epilogue == VGEN_EPI_GEGLU ? a.N / 2 : a.N;
@@ -916,6 +1023,20 @@ int launch(const vgen_tapgemm_args& a, int splitk, hipStream_t stream) {
 template <typename T>
 int dispatch(const vgen_tapgemm_args& a, hipStream_t s) {
   const Plan pl = make_plan(a);
+  if (a.dualw) {
+    if (pl.shape == SHAPE_PP128) {
+      switch (pl.bn) {
+        case 128: return launch<T, 128, 128, 64, 4, 2, 3, true, true>(a, pl.splitk, s);
+        case 160: return launch<T, 128, 160, 64, 4, 2, 3, true, true>(a, pl.splitk, s);
+        default: return launch<T, 128, 64, 64, 4, 2, 3, true, true>(a, pl.splitk, s);
+      }
+    }
+    switch (pl.bn) {
+      case 128: return launch<T, 256, 128, 64, 4, 2, 3, true, true>(a, pl.splitk, s);
+      case 160: return launch<T, 256, 160, 64, 4, 2, 3, true, true>(a, pl.splitk, s);
+      default: return launch<T, 256, 64, 64, 4, 2, 3, true, true>(a, pl.splitk, s);
+    }
+  }
   if (pl.shape == SHAPE_PP) {
     switch (pl.bn) {
       case 128: return launch<T, 256, 128, 64, 4, 2, 3, true>(a, pl.splitk, s);
@@ -985,9 +1106,10 @@ extern "C" int vgen_tapgemm(const vgen_tapgemm_args* args, void* stream) {
   VGEN_REQUIRE(a.M >= 0 && a.N > 0, "tapgemm: bad M/N");
   VGEN_REQUIRE(a.C1 > 0 && a.C1 % 64 == 0 && a.C2 >= 0 && a.C2 % 64 == 0,
                "tapgemm: C1=%d / C2=%d must be multiples of 64", a.C1, a.C2);
+  VGEN_REQUIRE(a.dualw == 0 || a.dualw == 1, "tapgemm: dualw must be 0 or 1");
   VGEN_REQUIRE(a.lda % 8 == 0 && (a.C2 == 0 || a.lda2 % 8 == 0) && a.ldw % 8 == 0 &&
-                   (a.ldw == 0 || a.ldw >= (int64_t)a.taps * a.C1 + a.C2),
-               "tapgemm: lda/lda2/ldw must be multiples of 8 (ldw >= K)");
+                   (a.ldw == 0 || a.ldw >= ((int64_t)a.taps * a.C1 + a.C2) * (a.dualw ? 2 : 1)),
+               "tapgemm: lda/lda2/ldw must be multiples of 8 (ldw >= K, 2 K with dualw)");
   VGEN_REQUIRE(vgen_aligned16(a.A) && vgen_aligned16(a.W) && vgen_aligned16(a.out) &&
                    (a.C2 == 0 || (a.A2 && vgen_aligned16(a.A2))),
                "tapgemm: pointers must be 16-byte aligned");
@@ -1019,7 +1141,8 @@ extern "C" int vgen_tapgemm(const vgen_tapgemm_args* args, void* stream) {
       return VGEN_E_BADARG;
   }
   VGEN_REQUIRE(a.M + 256 < (1LL << 31), "tapgemm: M overflows int32 row index");
-  VGEN_REQUIRE(((int64_t)a.taps * a.C1 + a.C2) * 2 <= ZERO_BYTES - 128, "tapgemm: K = %lld too long (<= 32704)",
+  VGEN_REQUIRE(((int64_t)a.taps * a.C1 + a.C2) * (a.dualw ? 4 : 2) <= ZERO_BYTES - 128,
+               "tapgemm: K = %lld too long (<= 131008; <= 65504 with dualw)",
                (long long)((int64_t)a.taps * a.C1 + a.C2));
   if (a.epilogue == VGEN_EPI_GEGLU) {
     VGEN_REQUIRE(a.N % 64 == 0 && a.rowbias == nullptr && (a.ldo % 4 == 0) &&

@@ -63,11 +63,8 @@ class DiffusionDDIM(object):
         self.posterior_mean_coef1 = betas * torch.sqrt(self.alphas_cumprod_prev) / (1.0 - self.alphas_cumprod)
         self.posterior_mean_coef2 = (1.0 - self.alphas_cumprod_prev) * torch.sqrt(alphas) / (1.0 - self.alphas_cumprod)
 
-        if var_type not in ("fixed_small", "fixed_large"):
-            # the reference's default 'learned_range' needs a 2*C-channel model output and the VLB terms; no
-            # inference config uses it — say so at construction rather than at the first sampling call
-            raise NotImplementedError(f"DiffusionDDIM(var_type={var_type!r}): learned variances are not on the "
-                                      "sampling path (configs use 'fixed_small'); vgen_amd builds the sampling side only")
+        # construction is as permissive as the reference's (its default var_type is 'learned_range', :34): DDIM sampling
+        # never reads var_type; the ancestral p_sample / p_mean_variance do and say so for the learned variants there
         self._tab = {}
         self._coef_tabs = {}
         self.sessions = SessionCache()  # per-(model, kwarg sets, shape) sampling sessions (vgen_amd/session.py)
@@ -207,6 +204,11 @@ class DiffusionDDIM(object):
     @torch.no_grad()
     def p_mean_variance(self, xt, t, model, model_kwargs={}, clamp=None, percentile=None, guide_scale=None):
         """Returns (mu, var, log_var, x0) like the reference; x0 comes from the fused kernel."""
+        if self.var_type not in ("fixed_small", "fixed_large"):
+            # 'learned' / 'learned_range' need a 2*C-channel model output and the VLB interpolation (:168-181); no
+            # inference config uses them (t2v_train.yaml: fixed_small)
+            raise NotImplementedError(f"p_mean_variance with var_type={self.var_type!r}: learned variances are not on "
+                                      "the sampling path (the inference configs use 'fixed_small')")
         _, x0 = self._fused(xt, t, model, model_kwargs, guide_scale, "x0", 0, 0.0, None, clamp, percentile)
         mu, var, log_var = self.q_posterior_mean_variance(x0, xt.float(), t)
         if self.var_type == "fixed_large":

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("VGEN_HIP_LIB") or os.path.join(HERE, "libvgen_hip.so"
 VGEN_BF16, VGEN_F16, VGEN_F32 = 0, 1, 2
 TAP_LINEAR, TAP_CONV3X3, TAP_TEMPORAL3 = 0, 1, 2
 EPI_NONE, EPI_GEGLU = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class VgenHipError(RuntimeError):
@@ -38,7 +38,7 @@ class TapGemmArgs(C.Structure):
         ("out", C.c_void_p), ("ldo", C.c_int64), ("out_dtype", C.c_int32),
         ("epilogue", C.c_int32),
         ("ws", C.c_void_p), ("ws_bytes", C.c_size_t), ("crop_t", C.c_int32),
-        ("colstats", C.c_void_p),
+        ("colstats", C.c_void_p), ("dualw", C.c_int32),
     ]
 
 

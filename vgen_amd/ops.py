@@ -113,33 +113,31 @@ def _mat(t: torch.Tensor, name: str):
     return t
 
 
+DW_TILE = 64   # K-tile granularity of the [W_hi | W_lo] interleave (include/vgen_hip.h: vgen_tapgemm_args.dualw)
+
+
 def split_weight(p32: torch.Tensor, dt) -> torch.Tensor:
-    """fp32 packed weight [N, K] -> its 16-bit rounding W_hi, carrying the rounding residual as a second 16-bit operand:
-    `vgen_lo` = round16(W - W_hi) (W_hi + W_lo reproduces W to ~2^-22 relative in fp16), `vgen_hilo` = [W_hi | W_lo] for
-    launches that can take the correction as a second K segment, `vgen_plain` = W_hi without the companions.  The
-    high-precision mode of the models (precision="high"): packed weights are the largest single rounding in the UNet
-     and the only one that can be removed without touching an activation."""
+    """fp32 packed weight [N, K] -> its 16-bit rounding W_hi, carrying as `.vgen_dw` the two-term operand of a dual-W
+    launch: [N, 2 K], every 64-column K-tile of W_hi followed by the same tile of W_lo = round16(W - W_hi) (W_hi + W_lo
+    reproduces W to ~2^-22 relative in fp16).  The high-precision mode of the models (precision="high"): packed weights
+    are the largest single rounding in the UNet and the only one that can be removed without touching an
+    activation.  A backend's tapgemm() that finds `.vgen_dw` on its W computes A . (W_hi + W_lo)^T in ONE launch that
+    stages every A K-tile once (vgen_tapgemm_args.dualw); as an A operand (the VAE's V^T product) the tensor is just
+    W_hi."""
+    N, K = p32.shape
+    assert K % DW_TILE == 0, f"packed K = {K} must be a multiple of {DW_TILE}"
     hi = p32.to(dt).contiguous()
-    lo = (p32.float() - hi.float()).to(dt).contiguous()
-    hi.vgen_lo = lo
-    hi.vgen_hilo = torch.cat([hi, lo], 1).contiguous()
-    hi.vgen_plain = hi.detach()
+    lo = (p32.float() - hi.float()).to(dt)
+    hi.vgen_dw = torch.stack([hi.view(N, K // DW_TILE, DW_TILE), lo.view(N, K // DW_TILE, DW_TILE)], 2) \
+        .reshape(N, 2 * K).contiguous()
     return hi
 
 
-def _tapgemm_weight_split(be, g: TapGemm):
-    """out = epi(A . (W_hi + W_lo)^T): a linear launch takes W_lo as its second K segment over the same rows (one
-    launch, K doubled, every epilogue as usual); gathers (3x3 / temporal taps) and launches that already use the second
-    segment run twice — W_hi with bias / row bias / residual into an fp32 temporary, then W_lo on top of it with the
-    launch's own output type, column statistics and workspace."""
-    import dataclasses
-    W = g.W
-    if g.mode == _lib.TAP_LINEAR and g.C2 == 0 and g.A2 is None:
-        return be.tapgemm(dataclasses.replace(g, W=W.vgen_hilo, A2=g.A, C2=g.C1))
-    assert g.epilogue == _lib.EPI_NONE, "GEGLU launches are linear"
-    lo = W.vgen_lo
-    t = be.tapgemm(dataclasses.replace(g, W=W.vgen_plain, out=None, out_dtype=torch.float32, colstats=False))
-    return be.tapgemm(dataclasses.replace(g, W=lo, bias=None, rowbias=None, rows_per_rb=0, residual=t))
+def dw_terms(dw: torch.Tensor):
+    """(W_hi, W_lo) [N, K] views of a dual-W operand [N, 2 K]."""
+    N, K2 = dw.shape
+    v = dw.view(N, K2 // (2 * DW_TILE), 2, DW_TILE)
+    return v[:, :, 0].reshape(N, K2 // 2), v[:, :, 1].reshape(N, K2 // 2)
 
 
 class HipBackend:
@@ -214,10 +212,10 @@ class HipBackend:
 
     # -- tap GEMM --------------------------------------------------------------------------
     def tapgemm(self, g: TapGemm):
-        if getattr(g.W, "vgen_lo", None) is not None:
-            return _tapgemm_weight_split(self, g)
         A = _mat(g.A, "A")
-        W = _mat(g.W, "W")
+        dw = getattr(g.W, "vgen_dw", None)          # two-term weight (precision="high"): one dual-W launch
+        W = _mat(g.W if dw is None else dw, "W")
+        K = g.taps * g.C1 + g.C2
         n_out = g.N // 2 if g.epilogue == _lib.EPI_GEGLU else g.N
         out = g.out
         if out is None:
@@ -236,7 +234,10 @@ class HipBackend:
             a.A2, a.lda2, a.C2 = A2.data_ptr(), A2.stride(0), g.C2
         assert W.dtype == A.dtype and W.shape[0] >= g.N
         a.W = W.data_ptr()
-        a.ldw = 0 if W.stride(0) == g.taps * g.C1 + g.C2 else W.stride(0)
+        if dw is not None:
+            assert W.shape[1] == 2 * K, (tuple(W.shape), K)
+            a.dualw = 1
+        a.ldw = 0 if W.stride(0) == K * (2 if dw is not None else 1) else W.stride(0)
         if g.bias is not None:
             assert g.bias.dtype == torch.float32 and g.bias.is_contiguous()
             a.bias = g.bias.data_ptr()
@@ -257,14 +258,15 @@ class HipBackend:
         if need:
             ws = torch.empty(need // 4, dtype=torch.float32, device=A.device)
             a.ws, a.ws_bytes = ws.data_ptr(), need
-        meta = (g.mode, g.M, g.N, g.taps * g.C1 + g.C2, g.epilogue, str(g.out_dtype))
+        meta = (g.mode, g.M, g.N, K, g.epilogue, str(g.out_dtype) + ("+dw" if dw is not None else ""))
         if KERNEL_PROFILE is not None and PROFILE_PLANS:
             # full launch signature of the plan table + the plan make_plan picks for it (tools/autotune_gemm.py)
             pl = (C.c_int32 * 3)()
             self.lib.vgen_tapgemm_query_plan(C.byref(a), pl)
             flags = (1 if g.residual is not None else 0) | (2 if g.rowbias is not None else 0) | (4 if cs is not None else 0)
             meta = meta + ((g.mode, g.M, g.N, g.C1, g.C2, g.taps, g.epilogue, _ENUM[g.out_dtype], flags), tuple(pl))
-        with self._Prof("tapgemm", 2.0 * g.M * g.N * (g.taps * g.C1 + g.C2), meta):
+        # algorithmic FLOP: the product A . W^T (a dual-W launch executes twice the MFMAs for the same product)
+        with self._Prof("tapgemm", 2.0 * g.M * g.N * K, meta):
             rc = self.lib.vgen_tapgemm(C.byref(a), self._stream(A))
         _lib.check(rc, "vgen_tapgemm")
         if cs is not None:

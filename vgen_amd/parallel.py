@@ -22,16 +22,36 @@ from __future__ import annotations
 
 from typing import List, Sequence
 
+import os
+
 import torch
 import torch.distributed as dist
 
+# test switch: run the all-gather even with a 1-rank group (exercises RCCL on a 1-GPU box)
+_FORCE_COLLECTIVE = os.environ.get("VGEN_FORCE_COLLECTIVE") == "1"
+
+
+# kwargs of the reference's UNets that are batched over the prompts (dim 0 = batch): y / fps / image / local_image of
+# UNetSD_T2VBase / I2VGen (unet_t2v.py:210-223, unet_i2vgen.py:243-262) and the composer conditions of VideoLCM / TFT2V
+# (unet_videolcm.py:541-560).  Everything else (config objects, flags, shared tensors) is passed through.
+PER_PROMPT_KEYS = frozenset({
+    "y", "fps", "image", "local_image", "depth", "sketch", "canny", "masked", "motion", "single_sketch", "histogram",
+    "video_mask", "focus_present_mask", "x_lr", "zero_y", "y_words"})
+
 
 def _slice_kwargs(kw, ps, P):
-    """kwargs of the prompts `ps`: every tensor batched over the P prompts is indexed, everything else is shared."""
+    """kwargs of the prompts `ps`.  Only the known per-prompt keys are indexed, and only when their leading dim IS
+    the prompt count; a per-prompt tensor given as a broadcast [1, ...] is expanded first.  (r02 indexed every tensor
+    whose leading dim happened to equal P and left broadcast rows unsliced: ADVICE r02.)"""
     out = {}
     for k, v in kw.items():
-        if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == P:
-            out[k] = v[ps]
+        if k in PER_PROMPT_KEYS and torch.is_tensor(v) and v.dim() >= 1:
+            if v.shape[0] == P:
+                out[k] = v[ps]
+            elif v.shape[0] == 1:
+                out[k] = v.expand(len(ps), *v.shape[1:])
+            else:
+                raise ValueError(f"kwarg {k!r}: leading dim {v.shape[0]} is neither the prompt count {P} nor 1")
         else:
             out[k] = v
     return out
@@ -45,6 +65,7 @@ class UnitPartition:
         from .session import SessionCache
         self.sessions = SessionCache()
         self._sub = {}              # (kwargs identity, local prompts) -> per-rank slices of the kwarg sets
+        self._gidx = {}             # (P, G, device) -> gather order of gather_grouped
 
     # -- unit -> (rank, slot) ----------------------------------------------------------------------
     # unit u = p * G + g.  Two layouts:
@@ -87,6 +108,34 @@ class UnitPartition:
         allb = mine.new_empty((self.world * S,) + tuple(mine.shape[1:]))
         dist.all_gather_into_tensor(allb, buf, group=self.group)
         return [allb[self.owner(u, P, G) * S + self.slot(u, P, G)] for u in range(U)]
+
+    def gather_grouped(self, mine: torch.Tensor, P: int, G: int):
+        """ONE all-gather of this rank's unit outputs (slot order), then the G per-branch batches [P, ...] every
+        sampler consumes — one index_select over the gathered buffer with a cached index (r02 built them with P-element
+        python lists and a torch.stack per branch on every step)."""
+        U = P * G
+        S = self.slots(U)
+        if self.world == 1 and not _FORCE_COLLECTIVE:
+            allb = mine
+        else:
+            if mine.shape[0] == S and mine.is_contiguous():
+                buf = mine
+            else:                                               # ragged tail: this rank owns fewer than S units
+                buf = mine.new_zeros((S,) + tuple(mine.shape[1:]))
+                buf[: mine.shape[0]].copy_(mine)
+            allb = mine.new_empty((self.world * S,) + tuple(mine.shape[1:]))
+            dist.all_gather_into_tensor(allb, buf, group=self.group)
+        key = (P, G, str(mine.device))
+        hit = self._gidx.get(key)
+        if hit is None:
+            # (g, p) -> position of unit u = p * G + g in the gathered buffer
+            pos = [self.owner(p * G + g, P, G) * S + self.slot(p * G + g, P, G) for g in range(G) for p in range(P)]
+            identity = pos == list(range(U))
+            hit = (None if identity else torch.tensor(pos, dtype=torch.long, device=mine.device), identity)
+            self._gidx[key] = hit
+        idx, identity = hit
+        ordered = allb[:U] if identity else allb.index_select(0, idx)
+        return tuple(ordered.view(G, P, *allb.shape[1:])[g] for g in range(G))
 
     def gather_units(self, mine: Sequence[torch.Tensor], U: int, like: torch.Tensor) -> List[torch.Tensor]:
         """List form of gather_stacked, 'unit' layout (each element shaped like `like`)."""
@@ -149,5 +198,4 @@ class UnitPartition:
                     outs[p * G + g] = o[i].float()
             local = torch.stack([outs[u] for u in mine]) if mine else \
                 xt.new_zeros((0,) + unit_shape, dtype=torch.float32)
-        allu = self.gather_stacked(local, U, P, G)
-        return tuple(torch.stack([allu[p * G + g] for p in range(P)]) for g in range(G))
+        return self.gather_grouped(local, P, G)

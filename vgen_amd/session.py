@@ -35,18 +35,34 @@ from . import ops
 _GRAPH_ON = os.environ.get("VGEN_GRAPH", "1") != "0"
 
 
+class Unkeyable(Exception):
+    """A kwarg value whose identity cannot be keyed (the caller then runs without a session)."""
+
+
+def _val_key(v):
+    """Identity key of one kwarg value: tensors by (id, version, shape, dtype) — also inside lists / tuples / dicts (a
+    repr() of a container of tensors elides its contents, so two conditionings could collide: ADVICE r02)."""
+    if torch.is_tensor(v):
+        # inference-mode tensors have no version counter: their identity + shape must do
+        ver = -1 if v.is_inference() else v._version
+        return ("T", id(v), ver, tuple(v.shape), v.dtype)
+    if isinstance(v, (list, tuple)):
+        return ("L", type(v).__name__) + tuple(_val_key(e) for e in v)
+    if isinstance(v, dict):
+        return ("D",) + tuple((str(k), _val_key(v[k])) for k in sorted(v, key=str))
+    if v is None or isinstance(v, (bool, int, float, str)):
+        return ("S", type(v).__name__, v)
+    try:
+        import numpy as np
+        if isinstance(v, np.ndarray):
+            return ("N", id(v), v.shape, str(v.dtype))
+    except ImportError:                                     # pragma: no cover
+        pass
+    raise Unkeyable(type(v).__name__)
+
+
 def _kw_key(kwargs_list):
-    key = []
-    for kw in kwargs_list:
-        items = []
-        for k in sorted(kw):
-            v = kw[k]
-            if torch.is_tensor(v):
-                items.append((k, id(v), v._version, tuple(v.shape), v.dtype))
-            else:
-                items.append((k, repr(v)))
-        key.append(tuple(items))
-    return tuple(key)
+    return tuple(tuple((k, _val_key(kw[k])) for k in sorted(kw)) for kw in kwargs_list)
 
 
 class UnitSession:
@@ -96,6 +112,10 @@ class UnitSession:
         if num_timesteps and not t_dtype.is_floating_point and self.fps is None:
             self.emb_tab = model.time_embedding_table(int(num_timesteps), self.device)
         self.use_graph = _GRAPH_ON and self.device.type == "cuda"
+        # every graph of this session (model-only, DDIM kinds / strides / etas, ...) captures into ONE private memory
+        # pool: a pool holds a whole forward's peak activations, and one pool per graph key kept several of them alive
+        # per prompt (tens of GB at 704p over a multi-prompt run: ADVICE r02)
+        self._pool = torch.cuda.graph_pool_handle() if self.use_graph else None
         self._graphs = {}
         self._static = {}
         self.xt_1 = torch.empty((self.B, self.C_lat, self.F, self.H, self.W), dtype=torch.float32, device=self.device)
@@ -145,7 +165,7 @@ class UnitSession:
             g = torch.cuda.CUDAGraph()
             try:
                 # thread_local: a watchdog thread of the process group may touch the runtime while we capture
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                with torch.cuda.graph(g, pool=self._pool, capture_error_mode="thread_local"):
                     launches()
             except Exception as ex:             # noqa: BLE001 — capture is an optimisation: stay correct, say so
                 warnings.warn(f"UnitSession: hipGraph capture failed ({type(ex).__name__}: {ex}); running eagerly")
@@ -197,9 +217,11 @@ class UnitSession:
 
 
 class SessionCache:
-    """Small LRU of UnitSessions (a handful of prompts / kwarg sets in flight)."""
+    """Small LRU of UnitSessions.  The engines build new kwarg tensors per prompt, so every prompt is a new session and
+    an old prompt's session (its graphs + their memory pool) is dead weight: capacity 2 = the prompt in flight plus
+    one sibling (e.g. the inversion pass and the CFG pass of the SR600 stage); `clear()` between prompts frees both."""
 
-    def __init__(self, capacity=4):
+    def __init__(self, capacity=2):
         self.capacity = capacity
         self._items = {}
 
@@ -207,7 +229,11 @@ class SessionCache:
         inner = getattr(model, "module", model)              # DistributedDataParallel wrapper of the engines
         if not hasattr(inner, "_prepare_units") or not hasattr(inner, "_body"):
             return None
-        key = (id(inner), inner._epoch, tuple(shape), str(device), _kw_key(kwargs_list), t_dtype, num_timesteps,
+        try:
+            kkey = _kw_key(kwargs_list)
+        except Unkeyable:
+            return None                                      # no stable identity: evaluate without a session
+        key = (id(inner), inner._epoch, tuple(shape), str(device), kkey, t_dtype, num_timesteps,
                None if units is None else tuple(units), ops.backend().name)
         s = self._items.pop(key, None)
         if s is None:

@@ -338,17 +338,43 @@ class AutoencoderKL(nn.Module):
         return ops.backend().frames_u8(o, self._u8_consts[1], self._u8_consts[2]).view(n, H, W, o.shape[1])
 
     @torch.no_grad()
-    def decode_video(self, latents, scale_factor=0.18215, decoder_bs=2, to_uint8=True, **u8):
+    def decode_video(self, latents, scale_factor=0.18215, decoder_bs=2, to_uint8=True, group=None, shard=None, **u8):
         """Engine glue a21 (inference_text2video_entrance.py:208-217): latents [B, 4, F, h, w] -> frames, i.e.
         `1/scale_factor * x`, '(b f) c h w' chunks of decoder_bs through decode, back to per-video order.
-        Returns uint8 [B, F, H, W, 3] (to_uint8) or fp32 [B, 3, F, H, W] like the reference."""
+        Returns uint8 [B, F, H, W, 3] (to_uint8) or fp32 [B, 3, F, H, W] like the reference.
+
+        Frame sharding ("the VAE shards by frame ... one final all-gather"): the AutoencoderKL is a per-frame
+        2-D network, so with an initialised process group (`shard` defaults to that; `group` selects it) every rank
+        decodes a contiguous block of ceil(B F / W) frames and ONE all_gather_into_tensor (RCCL over xGMI with the nccl
+        backend; 16 x 448 x 256 x 3 uint8 = 5.5 MB) hands every rank the whole video.  The latents must be the same
+        on all ranks — they are after the unit partition's redundant update (vgen_amd/parallel.py)."""
+        import torch.distributed as dist
         B, C, F, h, w = latents.shape
         z = (latents.float() * (1.0 / scale_factor)).permute(0, 2, 1, 3, 4).reshape(B * F, C, h, w)
+        n = B * F
+        inited = dist.is_available() and dist.is_initialized()
+        W_ = dist.get_world_size(group) if inited else 1
+        if shard is None:
+            shard = W_ > 1
+        shard = bool(shard) and inited         # shard=True with a 1-rank group still runs the collective (RCCL smoke test)
+        rank = dist.get_rank(group) if shard else 0
+        per = (n + W_ - 1) // W_ if shard else n                 # frames per rank (the last rank's block may be short)
+        lo, hi = min(rank * per, n), min((rank + 1) * per, n)
         outs = []
-        for i in range(0, B * F, decoder_bs):
-            zc = z[i:i + decoder_bs]
+        for i in range(lo, hi, decoder_bs):
+            zc = z[i:min(i + decoder_bs, hi)]
             outs.append(self.decode_to_uint8(zc, **u8) if to_uint8 else self.decode(zc))
-        o = torch.cat(outs, 0)
+        if not shard:
+            o = torch.cat(outs, 0)
+        else:
+            H, Wd = 8 * h, 8 * w
+            fshape = (H, Wd, 3) if to_uint8 else (3, H, Wd)
+            mine = torch.zeros((per,) + fshape, dtype=torch.uint8 if to_uint8 else torch.float32, device=latents.device)
+            if outs:
+                mine[: hi - lo].copy_(torch.cat(outs, 0))
+            allf = mine.new_empty((W_ * per,) + fshape)
+            dist.all_gather_into_tensor(allf, mine, group=group)   # the one collective of the decode
+            o = allf[:n]
         if to_uint8:
             return o.view(B, F, *o.shape[1:])
         return o.view(B, F, *o.shape[1:]).permute(0, 2, 1, 3, 4)
