@@ -172,6 +172,70 @@ def make_vcomposer(R):
 
 
 @torch.no_grad()
+def make_vae_full2(R):
+    """Full-size SD AutoencoderKL fixtures the r02 set lacked: `encode` moments + the stochastic
+    `encode_firsr_stage` sample at 256x448, and one 720x1280 frame through encode and decode (the SR600 stage runs 32
+    such frames, inference_tft2v_sr600_entrance.py:118; i2vgen encodes one, inference_i2vgen_entrance.py:193).
+    720p tensors are stored sub-sampled with their norms."""
+    import time
+    vae = R["AUTO_ENCODER"].build(dict(type="AutoencoderKL", ddconfig=VAE_SD, embed_dim=4)).eval()
+    vshapes = torch_ref.shapes_of(vae)
+    vae.load_state_dict(torch_ref.synth_state_dict(vshapes, seed=0), strict=True)
+    out = dict(ddconfig=VAE_SD, seed=0, shapes=vshapes)
+    with torch.no_grad():
+        g = torch.Generator("cpu").manual_seed(8890)
+        img = torch.randn(1, 3, 256, 448, generator=g).clamp(-1, 1)
+        t0 = time.time()
+        mom = vae.encode(img).parameters
+        torch.manual_seed(5)
+        zs = vae.encode_firsr_stage(img, 0.18215)
+        print("vae 256x448 encode x2: %.1f s" % (time.time() - t0))
+        out.update(enc256_seed=8890, enc256_moments=mom.contiguous(), enc256_sample_seed=5, enc256_z=zs.contiguous())
+        g = torch.Generator("cpu").manual_seed(8891)
+        img = torch.randn(1, 3, 720, 1280, generator=g).clamp(-1, 1)
+        t0 = time.time()
+        mom = vae.encode(img).parameters                                        # [1, 8, 90, 160]
+        print("vae 720x1280 encode: %.1f s" % (time.time() - t0))
+        out.update(enc720_seed=8891, enc720_moments_sub=mom[:, :, ::2, ::2].contiguous(), enc720_norm=float(mom.norm()))
+        z = torch.randn(1, 4, 90, 160, generator=g)
+        t0 = time.time()
+        dec = vae.decode(z)                                                      # [1, 3, 720, 1280]
+        print("vae 720x1280 decode: %.1f s" % (time.time() - t0))
+        out.update(dec720_sub=dec[:, :, ::8, ::8].contiguous(), dec720_norm=float(dec.norm()))
+    torch.save(out, os.path.join(GOLD, "vae_sd_full2.pt"))
+
+
+def make_i2vgen_full(R):
+    """The reference's FULL-WIDTH UNetSD_I2VGen (dim 320, 1420 M parameters) at BASELINE config 3's real latent
+    [1,4,16,88,160] (i2vgen_xl_infer.yaml: 16 frames 1280x704), 77 + 64 + 4 context tokens, local-image stem channels,
+    fps embedding: 88 TFLOP on the CPU.  Output stored sub-sampled (frames ::2, rows / cols ::4) with its norm."""
+    import time
+    cfg = dict(UNET_T2V, concat_dim=4, upper_len=128, default_fps=8, training=False)      # i2vgen_xl_train.yaml:32-51
+    ref = R["MODEL"].build(dict(type="UNetSD_I2VGen", **cfg)).eval()
+    shapes = torch_ref.shapes_of(ref)
+    ref.load_state_dict(torch_ref.synth_state_dict(shapes, seed=0), strict=True)
+    g = torch.Generator("cpu").manual_seed(8892)
+    x = torch.randn(1, 4, 16, 88, 160, generator=g)
+    y = torch.randn(1, 77, 1024, generator=g)
+    image = torch.randn(1, 1, 1024, generator=g)
+    local_image = torch.randn(1, 4, 88, 160, generator=g)
+    fps = torch.tensor([8])
+    t = torch.tensor([601])
+    _cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self           # mask_pos hard-codes .cuda() (unet_i2vgen.py:284)
+    try:
+        with torch.no_grad():
+            t0 = time.time()
+            out = ref(x, t, y=y, image=image, local_image=local_image, fps=fps)
+            print("unet_i2vgen full forward: %.1f s, std %.4f" % (time.time() - t0, float(out.std())))
+    finally:
+        torch.Tensor.cuda = _cuda
+    torch.save(dict(cfg=cfg, seed=0, shapes=shapes, input_seed=8892, t=t, fps=fps,
+                    out_sub=out[:, :, ::2, ::4, ::4].contiguous(), out_norm=float(out.norm())),
+               os.path.join(GOLD, "unet_i2vgen_full.pt"))
+
+
+
 def _no_cuda():
     """context: the reference hard-codes .cuda() in a few places (unet_i2vgen.py:284, unet_sr600.py:38)"""
     import contextlib
@@ -476,6 +540,12 @@ def main():
         return
     if args.only == "vae_blocks":
         make_vae_blocks(R)
+        return
+    if args.only == "vae_full2":
+        make_vae_full2(R)
+        return
+    if args.only == "i2vgen_full":
+        make_i2vgen_full(R)
         return
     torch.manual_seed(0)
 

@@ -257,7 +257,7 @@ class UNetSD_T2VBase(nn.Module):
         # "high": every packed weight also carries its 16-bit rounding residual and the GEMMs add A . W_lo — removes the
         # largest rounding category at ~2x the tap-GEMM time; set before the first forward / pack()
         self.precision = precision or "fast"
-        assert self.precision in ("fast", "high")
+        assert self.precision in ("fast", "high", "mixed")
 
         enc_dims = [dim * u for u in [1] + list(dim_mult)]
         dec_dims = [dim * u for u in [dim_mult[-1]] + list(dim_mult)[::-1]]
@@ -351,6 +351,20 @@ class UNetSD_T2VBase(nn.Module):
         with split_weights(self.precision == "high"):
             return self._pack(device)
 
+    # precision="mixed": two-term weights only where the output is most sensitive to the weight rounding.  The rule is
+    # structural (module position, not a per-fixture list): rounding errors made early in the encoder at full
+    # resolution pass through every later block and both skip paths, errors made in the deep levels and late in the
+    # decoder reach the output attenuated (per-module attribution: profiles/r03_weight_sensitivity.json,
+    # tools/parity_attrib.py --by-module --set w_lin,w_conv).
+    MIXED_SPLIT_PREFIXES = ()
+
+    def _wants_split(self, name):
+        if self.precision == "high":
+            return True
+        if self.precision == "mixed":
+            return any(name == p or name.startswith(p + ".") for p in self.MIXED_SPLIT_PREFIXES)
+        return False
+
     def _pack(self, device=None):
         dt = self.compute_dtype
         P = {}
@@ -378,7 +392,8 @@ class UNetSD_T2VBase(nn.Module):
             ws += [a2.to_k.weight, a2.to_v.weight]
             st._kv_off = off
             off += 2 * st.inner
-        P["kv_all"] = pack_linear(torch.cat(ws, 0), dt)
+        with split_weights(self._wants_split("kv_all")):
+            P["kv_all"] = pack_linear(torch.cat(ws, 0), dt)
         P["kv_width"] = off
 
         conv_in = self.input_blocks[0][0]
@@ -436,19 +451,21 @@ class UNetSD_T2VBase(nn.Module):
             return d
 
         for name, m in self.named_modules():
-            if isinstance(m, _ResBlockP):
-                P[name] = pack_res(m)
-            elif isinstance(m, _SpatialTransformerP):
-                P[name] = pack_tx(m, True)
-            elif isinstance(m, _TemporalTransformerP):
-                P[name] = pack_tx(m, False)
-            elif isinstance(m, _DownP):
-                P[name] = (pack_conv3x3(m.op.weight, dt), _f32(m.op.bias))
-            elif isinstance(m, _UpP):
-                P[name] = (pack_conv3x3(m.conv.weight, dt), _f32(m.conv.bias))
+            with split_weights(self._wants_split(name)):
+                if isinstance(m, _ResBlockP):
+                    P[name] = pack_res(m)
+                elif isinstance(m, _SpatialTransformerP):
+                    P[name] = pack_tx(m, True)
+                elif isinstance(m, _TemporalTransformerP):
+                    P[name] = pack_tx(m, False)
+                elif isinstance(m, _DownP):
+                    P[name] = (pack_conv3x3(m.op.weight, dt), _f32(m.op.bias))
+                elif isinstance(m, _UpP):
+                    P[name] = (pack_conv3x3(m.conv.weight, dt), _f32(m.conv.bias))
             m._pname = name
         P["head_gn"] = (_f32(self.out[0].weight), _f32(self.out[0].bias))
-        P["head_conv"] = (pack_conv3x3(self.out[2].weight, dt), _f32(self.out[2].bias))
+        with split_weights(self._wants_split("out")):
+            P["head_conv"] = (pack_conv3x3(self.out[2].weight, dt), _f32(self.out[2].bias))
         eye = torch.eye(self.out_dim, dtype=torch.float32, device=self.out[2].weight.device)
         P["eye"] = eye.contiguous()
         self._packed = P
