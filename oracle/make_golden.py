@@ -58,6 +58,58 @@ def dummy_model(x, t, y=None, **kw):
         + 0.001 * t.float().view(-1, 1, 1, 1, 1)
 
 
+def dummy_model4(x, t, y=None, **kw):
+    """dummy_model for 4-D "image" latents."""
+    w = torch.tensor([[0.6, -0.2, 0.1, 0.0], [0.1, 0.5, -0.3, 0.2], [-0.2, 0.1, 0.7, 0.1], [0.0, 0.3, -0.1, 0.4]])
+    return torch.einsum("oc,bchw->bohw", w.to(x), x) + 0.05 * y.float().mean() + 0.001 * t.float().view(-1, 1, 1, 1)
+
+
+def dummy_model2(x, t, y=None, **kw):
+    """2 C-channel stand-in (mean prediction | variance fraction) for the learned-variance branches."""
+    o = dummy_model4(x, t, y=y)
+    return torch.cat([o, torch.tanh(0.7 * o.flip(1)) * 0.8], dim=1)
+
+
+def make_ddim_branches(R):
+    """The sampler options no inference yaml uses, from the reference itself (diffusion_ddim.py:116-241): learned /
+    learned_range variances, mean_type 'x_{t-1}', clamp / percentile on x0, classifier guidance (condition_fn) — one
+    p_mean_variance, p_sample, ddim_sample and ddim_reverse_sample each, 4-D "image" latents (the reference's percentile
+    branch reshapes with view(-1, 1, 1, 1))."""
+    g = torch.Generator("cpu").manual_seed(31)
+    noise = torch.randn(2, 4, 8, 8, generator=g)
+    kw = [dict(y=torch.randn(2, 7, 16, generator=g)), dict(y=torch.randn(2, 7, 16, generator=g))]
+    t = torch.tensor([981, 21])
+    cond = lambda x, t, **k: 0.3 * torch.tanh(x)
+    base = {k: v for k, v in DDIM_T2V.items() if k not in ("var_type", "mean_type")}
+    res = dict(cfg=base, noise=noise, kw=kw, t=t, cases={})
+    cases = {
+        "learned_range_eps": dict(var_type="learned_range", mean_type="eps", model=2),
+        "learned_v": dict(var_type="learned", mean_type="v", model=2),
+        "xtm1_fixed_small": dict(var_type="fixed_small", mean_type="x_{t-1}", model=1),
+        "v_clamp": dict(var_type="fixed_small", mean_type="v", model=1, clamp=0.8),
+        "v_percentile": dict(var_type="fixed_large", mean_type="v", model=1, percentile=0.9),
+        "v_condfn": dict(var_type="fixed_small", mean_type="v", model=1, cond=True),
+    }
+    for name, c in cases.items():
+        d = R["DIFFUSION"].build(dict(type="DiffusionDDIM", **base, var_type=c["var_type"], mean_type=c["mean_type"]))
+        mdl = dummy_model2 if c["model"] == 2 else dummy_model4
+        opt = dict(clamp=c.get("clamp"), percentile=c.get("percentile"))
+        cf = cond if c.get("cond") else None
+        out = {}
+        out["pmv"] = [v.clone() for v in d.p_mean_variance(noise.clone(), t, mdl, kw, guide_scale=9.0, **opt)]
+        torch.manual_seed(7)
+        out["p_sample"] = [v.clone() for v in d.p_sample(noise.clone(), t, mdl, kw if cf is None else kw[0],
+                                                         condition_fn=cf, guide_scale=9.0 if cf is None else None, **opt)]
+        torch.manual_seed(8)
+        out["ddim"] = [v.clone() for v in d.ddim_sample(noise.clone(), t, mdl, kw if cf is None else kw[0], condition_fn=cf,
+                                                         guide_scale=9.0 if cf is None else None, ddim_timesteps=50, eta=0.5, **opt)]
+        out["reverse"] = [v.clone() for v in d.ddim_reverse_sample(noise.clone(), t, mdl, kw, guide_scale=9.0,
+                                                                   ddim_timesteps=50, **opt)]
+        res["cases"][name] = dict(c, **out)
+    torch.save(res, os.path.join(GOLD, "ddim_branches.pt"))
+    print("ddim_branches", list(res["cases"]))
+
+
 I2V_TINY = dict(in_dim=4, dim=64, y_dim=1024, context_dim=1024, concat_dim=4, out_dim=4, dim_mult=[1, 2, 4],
                 num_heads=2, head_dim=64, num_res_blocks=1, attn_scales=[1.0, 0.5, 0.25], dropout=0.1,
                 temporal_attention=True, temporal_attn_times=1, use_checkpoint=False, use_fps_condition=False,
@@ -540,6 +592,9 @@ def main():
         return
     if args.only == "vae_blocks":
         make_vae_blocks(R)
+        return
+    if args.only == "ddim_branches":
+        make_ddim_branches(R)
         return
     if args.only == "vae_full2":
         make_vae_full2(R)

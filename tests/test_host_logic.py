@@ -212,18 +212,38 @@ def test_ancestral_sampler_and_q_helpers_bit_exact_vs_reference_golden(emu_backe
     assert same(d.q_posterior_mean_variance(g["x0"], g["noise"], t), g["q_posterior"])
     torch.manual_seed(6)
     assert torch.equal(d.q_sample(g["x0"], t), g["q_sample"])
-    with pytest.raises(NotImplementedError):
-        d.p_sample(g["noise"], t, dummy_model, g["kw"], guide_scale=9.0, condition_fn=lambda *a, **k: 0)
-    # the reference's default var_type is 'learned_range' (diffusion_ddim.py:34): construction and DDIM sampling, which
-    # never reads it, work as in the reference; only the ancestral path that needs the learned variance says no
+    # the reference's default var_type is 'learned_range' (diffusion_ddim.py:34): construction works as in the reference
+    # (the learned-variance branches themselves: test_sampler_options_unused_by_the_configs_vs_reference_golden)
     cfg = {k: v for k, v in g["cfg"].items() if k != "var_type"}
     dl = DiffusionDDIM(**cfg)
     assert dl.var_type == "learned_range"
-    torch.manual_seed(5)
-    assert same(dl.ddim_sample(g["noise"].clone(), t, dummy_model, g["kw"], guide_scale=9.0, ddim_timesteps=50, eta=0.7),
-                g["ddim_eta"])
-    with pytest.raises(NotImplementedError):
-        dl.p_mean_variance(g["noise"], t, dummy_model, g["kw"], guide_scale=9.0)
+
+
+def test_sampler_options_unused_by_the_configs_vs_reference_golden(emu_backend):
+    """Learned / learned_range variances, mean_type 'x_{t-1}', clamp / percentile and classifier guidance against the
+    reference's own outputs (tests/golden/ddim_branches.pt, oracle/make_golden.py make_ddim_branches): p_mean_variance,
+    p_sample, a stochastic ddim_sample and ddim_reverse_sample each.  fp32 torch elementwise ops in the reference's
+    order: bit-exact."""
+    from oracle.make_golden import dummy_model2, dummy_model4
+    from vgen_amd.diffusion import DiffusionDDIM
+    g = gold("ddim_branches.pt")
+    same = lambda a, b: len(a) == len(b) and all(torch.equal(x.float(), y.float()) for x, y in zip(a, b))
+    cond = lambda x, t, **k: 0.3 * torch.tanh(x)
+    noise, kw, t = g["noise"], g["kw"], g["t"]
+    for name, c in g["cases"].items():
+        d = DiffusionDDIM(**g["cfg"], var_type=c["var_type"], mean_type=c["mean_type"])
+        mdl = dummy_model2 if c["model"] == 2 else dummy_model4
+        opt = dict(clamp=c.get("clamp"), percentile=c.get("percentile"))
+        cf = cond if c.get("cond") else None
+        assert same(d.p_mean_variance(noise.clone(), t, mdl, kw, guide_scale=9.0, **opt), c["pmv"]), name
+        torch.manual_seed(7)
+        assert same(d.p_sample(noise.clone(), t, mdl, kw if cf is None else kw[0], condition_fn=cf,
+                               guide_scale=9.0 if cf is None else None, **opt), c["p_sample"]), name
+        torch.manual_seed(8)
+        assert same(d.ddim_sample(noise.clone(), t, mdl, kw if cf is None else kw[0], condition_fn=cf,
+                                  guide_scale=9.0 if cf is None else None, ddim_timesteps=50, eta=0.5, **opt), c["ddim"]), name
+        assert same(d.ddim_reverse_sample(noise.clone(), t, mdl, kw, guide_scale=9.0, ddim_timesteps=50, **opt),
+                    c["reverse"]), name
 
 
 def test_ddim_call_pattern_and_rng_parity(emu_backend):

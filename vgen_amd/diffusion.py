@@ -134,7 +134,7 @@ class DiffusionDDIM(object):
         if self.mean_type == "x0":
             z = torch.zeros_like(tab[_AC][t])
             return z, z
-        raise NotImplementedError("mean_type 'x_{t-1}' is not on the sampling path")
+        raise NotImplementedError("mean_type 'x_{t-1}' takes the general path (_p_mean_variance_general)")
 
     def _coef_rows(self, tab, t, kind, stride, eta):
         """The 7 coefficients of vgen_cfg_ddim_step for timesteps `t` (any shape of long indices), fp32, in the
@@ -185,7 +185,7 @@ class DiffusionDDIM(object):
                alias_ok=False):
         """(x_next, x0) = fused CFG + x0 + update of `kind` ('ddim' | 'reverse' | 'x0') after evaluating the model."""
         if clamp is not None or percentile is not None:
-            raise NotImplementedError("clamp / percentile are unused by the inference configs")
+            raise NotImplementedError("clamp / percentile take the general path (_p_mean_variance_general)")
         sess = self._session(xt, t, model, model_kwargs, guide_scale)
         if sess is not None:
             return sess.ddim_step(xt, t, self._coef_table(xt.device, kind, stride, eta),
@@ -200,15 +200,68 @@ class DiffusionDDIM(object):
                                            0.0 if guide_scale is None else float(guide_scale),
                                            guide_scale is not None, _MEAN[self.mean_type], True)
 
+    # -- the options no inference config uses ------------------------------------------------------
+    def _uncommon(self, clamp, percentile):
+        return clamp is not None or percentile is not None or self.mean_type == "x_{t-1}" \
+            or self.var_type in ("learned", "learned_range")
+
+    def _p_mean_variance_general(self, xt, t, model, model_kwargs, clamp, percentile, guide_scale):
+        """p_mean_variance with the reference's rarely used options — learned / learned_range variances (a 2 C-channel
+        model output, diffusion_ddim.py:164-177), mean_type 'x_{t-1}' (:184-187), clamp / percentile on x0 (:199-204).
+        The model is still evaluated through `_eval_model` (the HIP units); the algebra on the latent-sized tensors is
+        written with a handful of torch elementwise ops in the reference's expression order (off the benchmarked path:
+        the fused kernel covers what the inference yamls use)."""
+        y_out, u_out = self._eval_model(xt, t, model, model_kwargs, guide_scale)
+        if u_out is None:
+            out = y_out.float()
+        else:
+            y_out, u_out = y_out.float(), u_out.float()
+            dim = y_out.size(1) if self.var_type.startswith("fixed") else y_out.size(1) // 2
+            out = torch.cat([u_out[:, :dim] + guide_scale * (y_out[:, :dim] - u_out[:, :dim]), y_out[:, dim:]], dim=1)
+        xt = xt.float()
+        g = lambda tab: self._g(tab, t, xt)
+        if self.var_type == "learned":
+            out, log_var = out.chunk(2, dim=1)
+            var = torch.exp(log_var)
+        elif self.var_type == "learned_range":
+            out, fraction = out.chunk(2, dim=1)
+            min_log_var = g(self.posterior_log_variance_clipped)
+            max_log_var = g(torch.log(self.betas))
+            fraction = (fraction + 1) / 2.0
+            log_var = fraction * max_log_var + (1 - fraction) * min_log_var
+            var = torch.exp(log_var)
+        elif self.var_type == "fixed_large":
+            var = g(torch.cat([self.posterior_variance[1:2], self.betas[1:]]))
+            log_var = torch.log(var)
+        else:
+            var = g(self.posterior_variance)
+            log_var = g(self.posterior_log_variance_clipped)
+        if self.mean_type == "x_{t-1}":
+            mu = out
+            x0 = g(1.0 / self.posterior_mean_coef1) * mu - g(self.posterior_mean_coef2 / self.posterior_mean_coef1) * xt
+        else:
+            if self.mean_type == "x0":
+                x0 = out
+            elif self.mean_type == "eps":
+                x0 = g(self.sqrt_recip_alphas_cumprod) * xt - g(self.sqrt_recipm1_alphas_cumprod) * out
+            else:
+                x0 = g(self.sqrt_alphas_cumprod) * xt - g(self.sqrt_one_minus_alphas_cumprod) * out
+            mu, _, _ = self.q_posterior_mean_variance(x0, xt, t)
+        if percentile is not None:
+            assert percentile > 0 and percentile <= 1
+            sh = (-1,) + (1,) * (x0.ndim - 1)           # the reference's view(-1, 1, 1, 1) serves 4-D images only
+            sq = torch.quantile(x0.flatten(1).abs(), percentile, dim=1).clamp_(1.0).view(*sh)
+            x0 = torch.min(sq, torch.max(-sq, x0)) / sq
+        elif clamp is not None:
+            x0 = x0.clamp(-clamp, clamp)
+        return mu, var, log_var, x0
+
     # -- p(x_{t-1} | x_t) pieces used by the samplers ---------------------------------------------
     @torch.no_grad()
     def p_mean_variance(self, xt, t, model, model_kwargs={}, clamp=None, percentile=None, guide_scale=None):
         """Returns (mu, var, log_var, x0) like the reference; x0 comes from the fused kernel."""
-        if self.var_type not in ("fixed_small", "fixed_large"):
-            # 'learned' / 'learned_range' need a 2*C-channel model output and the VLB interpolation (:168-181); no
-            # inference config uses them (t2v_train.yaml: fixed_small)
-            raise NotImplementedError(f"p_mean_variance with var_type={self.var_type!r}: learned variances are not on "
-                                      "the sampling path (the inference configs use 'fixed_small')")
+        if self._uncommon(clamp, percentile):
+            return self._p_mean_variance_general(xt, t, model, model_kwargs, clamp, percentile, guide_scale)
         _, x0 = self._fused(xt, t, model, model_kwargs, guide_scale, "x0", 0, 0.0, None, clamp, percentile)
         mu, var, log_var = self.q_posterior_mean_variance(x0, xt.float(), t)
         if self.var_type == "fixed_large":
@@ -219,11 +272,12 @@ class DiffusionDDIM(object):
     @torch.no_grad()
     def p_sample(self, xt, t, model, model_kwargs={}, clamp=None, percentile=None, condition_fn=None, guide_scale=None):
         """One ancestral step x_t -> x_{t-1} ~ N(mu, var) (diffusion_ddim.py:116-132); returns (x_{t-1}, x0)."""
-        if condition_fn is not None:
-            raise NotImplementedError("classifier guidance (condition_fn) is unused by the inference configs")
         mu, var, log_var, x0 = self.p_mean_variance(xt, t, model, model_kwargs, clamp, percentile, guide_scale)
         noise = torch.randn_like(xt)
         mask = t.ne(0).float().view(-1, *((1,) * (xt.ndim - 1)))      # no noise when t == 0
+        if condition_fn is not None:                                  # classifier guidance (:127-130)
+            grad = condition_fn(xt, self._scale_timesteps(t), **model_kwargs)
+            mu = mu.float() + var * grad.float()
         return mu + mask * torch.exp(0.5 * log_var) * noise, x0
 
     @torch.no_grad()
@@ -243,9 +297,10 @@ class DiffusionDDIM(object):
         """One DDIM step (diffusion_ddim.py:208-241).  For vgen_amd models the whole step — both CFG branches as
         one UNet batch plus the fused update — is a hipGraph replay of a cached sampling session; any other
         `model` callable runs eagerly through the same update kernel."""
-        if condition_fn is not None:
-            raise NotImplementedError("classifier guidance (condition_fn) is unused by the inference configs")
         stride = self.num_timesteps // ddim_timesteps
+        if condition_fn is not None or self._uncommon(clamp, percentile):
+            return self._ddim_sample_general(xt, t, model, model_kwargs, clamp, percentile, condition_fn, guide_scale,
+                                             stride, eta)
         noise = None
         if self.rng_parity or eta != 0.0:
             noise = torch.randn_like(xt)             # drawn every step by the reference (:237)
@@ -254,6 +309,26 @@ class DiffusionDDIM(object):
         return self._fused(xt, t, model, model_kwargs, guide_scale, "ddim", stride, eta,
                            noise if noise is None else noise.float().contiguous(), clamp, percentile,
                            alias_ok=_alias_ok)
+
+    def _ddim_sample_general(self, xt, t, model, model_kwargs, clamp, percentile, condition_fn, guide_scale, stride, eta):
+        """ddim_sample with the options of `_p_mean_variance_general` and / or classifier guidance (diffusion_ddim.py:
+        217-241 in the reference's expression order)."""
+        _, _, _, x0 = self._p_mean_variance_general(xt, t, model, model_kwargs, clamp, percentile, guide_scale)
+        xt = xt.float()
+        g = lambda tab: self._g(tab, t, xt)
+        if condition_fn is not None:
+            alpha = g(self.alphas_cumprod)
+            eps = (g(self.sqrt_recip_alphas_cumprod) * xt - x0) / g(self.sqrt_recipm1_alphas_cumprod)
+            eps = eps - (1 - alpha).sqrt() * condition_fn(xt, self._scale_timesteps(t), **model_kwargs)
+            x0 = g(self.sqrt_recip_alphas_cumprod) * xt - g(self.sqrt_recipm1_alphas_cumprod) * eps
+        eps = (g(self.sqrt_recip_alphas_cumprod) * xt - x0) / g(self.sqrt_recipm1_alphas_cumprod)
+        alphas = g(self.alphas_cumprod)
+        alphas_prev = self._g(self.alphas_cumprod, (t - stride).clamp(0), xt)
+        sigmas = eta * torch.sqrt((1 - alphas_prev) / (1 - alphas) * (1 - alphas / alphas_prev))
+        noise = torch.randn_like(xt)
+        direction = torch.sqrt(1 - alphas_prev - sigmas ** 2) * eps
+        mask = t.ne(0).float().view(-1, *((1,) * (xt.ndim - 1)))
+        return torch.sqrt(alphas_prev) * x0 + direction + mask * sigmas * noise, x0
 
     @torch.no_grad()
     def ddim_sample_loop(self, noise, model, model_kwargs={}, clamp=None, percentile=None,
@@ -275,6 +350,13 @@ class DiffusionDDIM(object):
         """x_t -> x_{t+stride} along the deterministic DDIM ODE (diffusion_ddim.py:256-274):
         mu = sqrt(a_next) * x0 + sqrt(1 - a_next) * eps — the same kernel with sigma = 0."""
         stride = self.num_timesteps // ddim_timesteps
+        if self._uncommon(clamp, percentile):
+            _, _, _, x0 = self._p_mean_variance_general(xt, t, model, model_kwargs, clamp, percentile, guide_scale)
+            xt = xt.float()
+            eps = (self._g(self.sqrt_recip_alphas_cumprod, t, xt) * xt - x0) / self._g(self.sqrt_recipm1_alphas_cumprod, t, xt)
+            alphas_next = self._g(torch.cat([self.alphas_cumprod, self.alphas_cumprod.new_zeros([1])]),
+                                  (t + stride).clamp(0, self.num_timesteps), xt)
+            return torch.sqrt(alphas_next) * x0 + torch.sqrt(1 - alphas_next) * eps, x0
         return self._fused(xt, t, model, model_kwargs, guide_scale, "reverse", stride, 0.0, None, clamp, percentile,
                            alias_ok=_alias_ok)
 
