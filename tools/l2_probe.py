@@ -2,6 +2,9 @@
 bit 3 makes every block stage tile (0, 0)'s operands (all DMA traffic hits the L2); bit 1 drops the epilogue stores."""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+# the phase-ablation / plan-override switches exist only in the TUNING build of the library (-DVGEN_TUNING,
+# vgen_amd/build.py build(tuning=True) -> libvgen_hip_tuning.so; build it in the container before gpurun ships the tree)
+os.environ.setdefault("VGEN_HIP_LIB", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "vgen_amd", "libvgen_hip_tuning.so"))
 import torch
 from vgen_amd import ops, lib as L
 from vgen_amd.ops import TapGemm
