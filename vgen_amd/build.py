@@ -40,13 +40,16 @@ def _stale(target: str, deps) -> bool:
 TUNING_LIB = os.path.join(HERE, "libvgen_hip_tuning.so")
 
 
-def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, tuning: bool = False, variant: str = "", defines=()) -> str:
     """tuning=True builds libvgen_hip_tuning.so with -DVGEN_TUNING: the tap-GEMM's phase-ablation switches and plan
     overrides (environment variables read per launch) exist only there — tools/ select it with VGEN_HIP_LIB; the product
-    library cannot be told to skip work."""
-    obj_dir = OBJ + ("_tuning" if tuning else "")
-    lib_path = TUNING_LIB if tuning else LIB
-    flags = FLAGS + (["-DVGEN_TUNING"] if tuning else [])
+    library cannot be told to skip work.  variant / defines: an experimental build libvgen_hip_<variant>.so with extra
+    -D flags, for same-box A/B runs of two kernel versions (VGEN_HIP_LIB=...; tools/ab_libs.sh)."""
+    if tuning:
+        variant, defines = "tuning", tuple(defines) + ("VGEN_TUNING",)
+    obj_dir = OBJ + ("_" + variant if variant else "")
+    lib_path = os.path.join(HERE, f"libvgen_hip_{variant}.so") if variant else LIB
+    flags = FLAGS + ["-D" + d for d in defines]
     os.makedirs(obj_dir, exist_ok=True)
     hipcc = _hipcc()
     jobs = []
@@ -75,4 +78,6 @@ def build(force: bool = False, verbose: bool = False, tuning: bool = False) -> s
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv, verbose=True, tuning="--tuning" in sys.argv))
+    _var = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--variant=")), "")
+    print(build(force="--force" in sys.argv, verbose=True, tuning="--tuning" in sys.argv, variant=_var,
+                defines=tuple(a[2:] for a in sys.argv if a.startswith("-D"))))

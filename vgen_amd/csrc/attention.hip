@@ -179,22 +179,41 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(const vgen_attn_args p, i
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[f], mx);  // finite: every tile has >= 1 valid key
-      const float alpha = fast_exp2((m_run[f] - m_new) * c);
-      m_run[f] = m_new;
+      // The running maximum settles after the first few KV tiles; when NO lane of the wave saw a larger score the
+      // rescale factor is exp2(0) = 1 for every query: skip its exponential and the 18 multiplies (wave-uniform
+      // branch; the result is bit-identical either way).
+      const bool grew = __builtin_amdgcn_ballot_w64(m_new > m_run[f]) != 0ull;
       const float mc = m_new * c;
-      float psum = 0.f;
       float pv[4][4];
+      // scores -> probabilities two at a time: v_pk_fma_f32 / v_pk_add_f32 do the scale-and-shift and the row sum in half
+      // the issue slots (the softmax, not the 32 MFMAs, bounds this kernel: ~350 VALU issue slots per KV tile and wave,
+      // the 32 quarter-rate v_exp_f32 included).  Same-box A/B, whole step: 42.05 -> 41.81 ms (high), 31.40 -> 31.15 ms
+      // (fast): profiles/r03b_ab_libs.jsonl
+      const f32x2 c2 = {c, c}, mc2 = {mc, mc};
+      f32x2 ps2 = {0.f, 0.f};
 #pragma unroll
-      for (int kf = 0; kf < 4; ++kf)
+      for (int kf = 0; kf < 4; ++kf) {
+        const f32x2 a = f32x2{s[f][kf][0], s[f][kf][1]} * c2 - mc2;
+        const f32x2 b = f32x2{s[f][kf][2], s[f][kf][3]} * c2 - mc2;
+        const f32x2 ea = {fast_exp2(a.x), fast_exp2(a.y)};
+        const f32x2 eb = {fast_exp2(b.x), fast_exp2(b.y)};
+        pv[kf][0] = ea.x;
+        pv[kf][1] = ea.y;
+        pv[kf][2] = eb.x;
+        pv[kf][3] = eb.y;
+        ps2 += ea;
+        ps2 += eb;
+      }
+      const float psum = ps2.x + ps2.y;
+      if (grew) {
+        const float alpha = fast_exp2((m_run[f] - m_new) * c);
+        m_run[f] = m_new;
+        l_run[f] = l_run[f] * alpha + psum;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float e = fast_exp2(s[f][kf][r] * c - mc);
-          pv[kf][r] = e;
-          psum += e;
-        }
-      l_run[f] = l_run[f] * alpha + psum;
-#pragma unroll
-      for (int d = 0; d < 4; ++d) o_acc[f][d] *= alpha;
+        for (int d = 0; d < 4; ++d) o_acc[f][d] *= alpha;
+      } else {
+        l_run[f] += psum;
+      }
       // B operand of the PV product for key-step st: keys {32st + 4lq + r} U {32st + 16 + 4lq + r}
 #pragma unroll
       for (int st = 0; st < 2; ++st) {

@@ -356,14 +356,44 @@ class UNetSD_T2VBase(nn.Module):
     # resolution pass through every later block and both skip paths, errors made in the deep levels and late in the
     # decoder reach the output attenuated (per-module attribution: profiles/r03_weight_sensitivity.json,
     # tools/parity_attrib.py --by-module --set w_lin,w_conv).
-    MIXED_SPLIT_PREFIXES = ()
+    MIXED_LEVELS = {"enc": (0, 1), "mid": (), "dec": (0, 1)}      # resolution levels (0 = full) whose blocks are split
+
+    def _block_levels(self):
+        """top-level block name ('input_blocks.3', 'middle_block', 'output_blocks.7') -> (side, resolution level), the
+        constructor's own bookkeeping of `scale` replayed (unet_t2v.py:110-202)."""
+        lv, level = {}, 0
+        nres, nmult = self.num_res_blocks, len(self.dim_mult)
+        idx = 0
+        lv["input_blocks.0"] = ("enc", 0)
+        for i in range(nmult):
+            for j in range(nres):
+                idx += 1
+                lv[f"input_blocks.{idx}"] = ("enc", level)
+                if i != nmult - 1 and j == nres - 1:
+                    idx += 1
+                    lv[f"input_blocks.{idx}"] = ("enc", level)           # the Downsample conv reads level `level`
+                    level += 1
+        lv["middle_block"] = ("mid", level)
+        idx = 0
+        for i in range(nmult):
+            for j in range(nres + 1):
+                lv[f"output_blocks.{idx}"] = ("dec", level)
+                if i != nmult - 1 and j == nres:
+                    level -= 1                                           # its Upsample conv writes the next finer level
+                idx += 1
+        return lv
 
     def _wants_split(self, name):
         if self.precision == "high":
             return True
-        if self.precision == "mixed":
-            return any(name == p or name.startswith(p + ".") for p in self.MIXED_SPLIT_PREFIXES)
-        return False
+        if self.precision != "mixed":
+            return False
+        if name in ("kv_all", "out"):                                    # context K/V projection, head conv: full resolution
+            return 0 in self.MIXED_LEVELS["enc"] or 0 in self.MIXED_LEVELS["dec"]
+        parts = name.split(".")
+        top = parts[0] if parts[0] == "middle_block" else ".".join(parts[:2])
+        side, level = self._block_levels().get(top, (None, None))
+        return side is not None and level in self.MIXED_LEVELS[side]
 
     def _pack(self, device=None):
         dt = self.compute_dtype
