@@ -323,7 +323,12 @@ int vgen_gaussian_sample(const float* moments, const float* noise, int64_t nimg,
  *   x0 = (xt - sigma*out)/alpha (pred_type 0 'eps') | alpha*xt - sigma*out (1 'v') | out (2 'x0'),
  *   eps = (xt - alpha*x0)/sigma (optional).  coef = [B][2] fp32 (alpha, sigma).
  * vgen_lincomb4 : out = ca*a + cb*b + cc*c + cd*d (NULL operands skipped, fp32, no contraction):
- *   the exponential-integrator / midpoint-correction / noise-injection update of DPM-Solver++(2M).
+ *   scalings around the model call of DPM-Solver++(2M).
+ * vgen_dpmpp2m_sde_step: ONE solver update (diffusion_gauss.py:126-139), every intermediate rounded where the
+ *   reference's three tensor statements round:  r = ca*x + cb*denoised;  old_denoised != NULL (2M correction, :131-136):
+ *   r = r + cc*denoised - cc*old_denoised;  noise != NULL (SDE term, :138-139): r = r + cn*noise.  ca = sigma_next /
+ *   sigma * exp(-eta h), cb = -expm1(-h - eta h), cc = midpoint / Heun coefficient / r, cn = sigma_next *
+ *   sqrt(-expm1(-2 eta h)) * s_noise — host scalars in the reference's own expressions.
  */
 /* FreeU-style skip filter of UNetSD_SR600 (unet_sr600.py:30-49, 276-287), on rows [nimg*H*W, C] fp32:
  * Fourier_filter(x, threshold=1, scale) multiplies the 2x2 block of centred-spectrum bins
@@ -376,6 +381,8 @@ int vgen_gauss_x0(const float* xt, const float* out, const void* ws, float resca
                   int32_t pred_type, int64_t B, int64_t per_b, float* x0, float* eps, void* stream);
 int vgen_lincomb4(const float* a, const float* b, const float* c, const float* d, float ca, float cb,
                   float cc, float cd, float* out, int64_t n, void* stream);
+int vgen_dpmpp2m_sde_step(const float* x, const float* denoised, const float* old_denoised, const float* noise,
+                          float ca, float cb, float cc, float cn, float* out, int64_t n, void* stream);
 
 #ifdef __cplusplus
 }

@@ -332,6 +332,15 @@ class EmuBackend:
                 r = r + f(cf) * t
         return r
 
+    def dpmpp2m_sde_step(self, x, denoised, old, noise, ca, cb, cc, cn):
+        # vgen_dpmpp2m_sde_step: the three statements of diffusion_gauss.py:126-139, each rounded like a lincomb4
+        r = self.lincomb4(x, denoised, None, None, ca, cb, 0, 0)
+        if old is not None:
+            r = self.lincomb4(r, denoised, old, None, 1.0, cc, -cc, 0)
+        if noise is not None:
+            r = self.lincomb4(r, noise, None, None, 1.0, cn, 0, 0)
+        return r
+
     def gaussian_sample(self, moments, noise, nimg, zc, HW, scale):
         m = moments.view(nimg, HW, 2 * zc)
         mean = m[..., :zc].permute(0, 2, 1).reshape(noise.shape)

@@ -37,8 +37,17 @@ def load():
     if REF not in sys.path:
         sys.path.insert(0, REF)
     xf, xo = types.ModuleType("xformers"), types.ModuleType("xformers.ops")
-    xo.memory_efficient_attention = lambda q, k, v, attn_bias=None, op=None: \
-        F.scaled_dot_product_attention(q, k, v)
+    def _mea(q, k, v, attn_bias=None, op=None):
+        # [B*heads, M, 64] sequences are independent: above ~2 GB of fp32 scores evaluate them in batch chunks (the
+        # 14 080-token self-attention of the 704p / 720p latents would need 63 GB at once on the CPU) — same numbers
+        import torch as _t
+        per = q.shape[1] * k.shape[1] * 4
+        n = max(1, int(2e9 // max(per, 1)))
+        if q.dim() != 3 or q.shape[0] <= n:
+            return F.scaled_dot_product_attention(q, k, v)
+        return _t.cat([F.scaled_dot_product_attention(q[i:i + n], k[i:i + n], v[i:i + n]) for i in range(0, q.shape[0], n)], 0)
+
+    xo.memory_efficient_attention = _mea
     xo.LowerTriangularMask = type("LowerTriangularMask", (), {})
     xf.ops = xo
     sys.modules.update({"xformers": xf, "xformers.ops": xo, "open_clip": types.ModuleType("open_clip")})

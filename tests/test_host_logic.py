@@ -99,6 +99,50 @@ def test_high_precision_mode_splits_every_packed_weight(emu_backend):
     assert plain == [0], plain                                      # the stem conv (its own 3-segment split)
 
 
+def test_mixed_precision_splits_by_resolution_level(emu_backend):
+    """precision="mixed": two-term weights exactly in the blocks of the resolution levels named by MIXED_LEVELS (the
+    constructor's own scale bookkeeping replayed), plain 16-bit weights elsewhere; the error lands between the two pure
+    modes."""
+    from vgen_amd.unet import UNetSD_T2VBase
+    m, g, sd = _unet("fp16")
+    mm = UNetSD_T2VBase(**g["cfg"], compute_dtype="fp16", precision="mixed").eval()
+    mm.MIXED_LEVELS = {"enc": (0,), "mid": (), "dec": (0,)}
+    mm.load_state_dict(sd, strict=True)
+    lv = mm._block_levels()
+    assert lv["input_blocks.0"] == ("enc", 0) and lv["middle_block"][0] == "mid"
+    assert max(l for _, l in lv.values()) == len(g["cfg"]["dim_mult"]) - 1
+    assert {k.split(".")[0] for k in lv} == {"input_blocks", "middle_block", "output_blocks"}
+    assert len([k for k in lv if k.startswith("output_blocks")]) == len(mm.output_blocks)
+    assert len([k for k in lv if k.startswith("input_blocks")]) == len(mm.input_blocks)
+    P = mm.pack()
+
+    def first_weight(d):
+        for v in d.values():
+            v = v[0] if isinstance(v, tuple) else v
+            if isinstance(v, dict):
+                return first_weight(v)
+            if torch.is_tensor(v) and v.dtype == torch.float16:
+                return v
+        raise KeyError
+
+    n_split = n_plain = 0
+    for name, mod in mm.named_modules():
+        if type(mod).__name__ in ("_ResBlockP", "_SpatialTransformerP", "_TemporalTransformerP"):
+            top = "middle_block" if name.startswith("middle_block") else ".".join(name.split(".")[:2])
+            side, level = lv[top]
+            has = getattr(first_weight(P[name]), "vgen_dw", None) is not None
+            assert has == (level == 0 and side != "mid"), (name, side, level, has)
+            n_split += has
+            n_plain += not has
+    assert n_split > 0 and n_plain > 0
+    e_fast = rel_l2(m(g["x"], g["t"], y=g["y"]), g["out"])
+    mh = UNetSD_T2VBase(**g["cfg"], compute_dtype="fp16", precision="high").eval()
+    mh.load_state_dict(sd, strict=True)
+    e_high = rel_l2(mh(g["x"], g["t"], y=g["y"]), g["out"])
+    e_mixed = rel_l2(mm(g["x"], g["t"], y=g["y"]), g["out"])
+    assert e_high <= e_mixed * 1.02 and e_mixed < e_fast, (e_fast, e_mixed, e_high)
+
+
 def test_dual_w_launch_semantics_vs_fp32_weights(emu_backend):
     """The dual-W cases of the GPU suite on the emulator: A . (W_hi + W_lo)^T reproduces the product with the unrounded
     fp32 weight to the residual of the split (2^-22 fp16 / 2^-17 bf16), through plain-torch operators on NCHW tensors."""

@@ -198,18 +198,19 @@ class GaussianDiffusion(object):
                     eta_h = eta * h
                     ca = float(sig[i + 1] / sig[i] * (-eta_h).exp())
                     cb = float((-h - eta_h).expm1().neg())
-                    x = be.lincomb4(x, denoised, None, None, ca, cb, 0, 0)
-                    if old_denoised is not None:
+                    cc, use_old = 0.0, old_denoised is not None
+                    if use_old:
                         r = h_last / h
                         if solver_type == "heun":
                             cc = float(((-h - eta_h).expm1().neg() / (-h - eta_h) + 1) * (1 / r))
                         else:
                             cc = float(0.5 * (-h - eta_h).expm1().neg() * (1 / r))
-                        x = be.lincomb4(x, denoised, old_denoised, None, 1.0, cc, -cc, 0)
                     cn = float(sig[i + 1] * (-2 * eta_h).expm1().neg().sqrt() * s_noise)
+                    nz = None
                     if cn != 0.0:
                         nz = sampler(sig[i], sig[i + 1]).to(device=x.device, dtype=torch.float32).contiguous()
-                        x = be.lincomb4(x, nz, None, None, 1.0, cn, 0, 0)
+                    # exponential-integrator step + 2M correction + noise injection: ONE launch (vgen_dpmpp2m_sde_step)
+                    x = be.dpmpp2m_sde_step(x, denoised, old_denoised if use_old else None, nz, ca, cb, cc, cn)
             old_denoised = denoised
             h_last = h
         return x

@@ -97,6 +97,7 @@ SYMBOLS = {
     "vgen_cfg_stats": (C.c_int, [_vp, _vp, _f32, _i32, _i64, _i64, _vp, _vp, _sz, _vp]),
     "vgen_gauss_x0": (C.c_int, [_vp, _vp, _vp, _f32, _vp, _i32, _i64, _i64, _vp, _vp, _vp]),
     "vgen_lincomb4": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _i64, _vp]),
+    "vgen_dpmpp2m_sde_step": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _i64, _vp]),
 }
 
 _lib = None

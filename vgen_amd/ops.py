@@ -488,6 +488,16 @@ class HipBackend:
         _lib.check(rc, "vgen_lincomb4")
         return out
 
+    def dpmpp2m_sde_step(self, x, denoised, old, noise, ca, cb, cc, cn):
+        """One DPM-Solver++(2M) SDE update in one launch (vgen_dpmpp2m_sde_step)."""
+        for t in (x, denoised, old, noise):
+            assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+        out = torch.empty_like(x)
+        rc = self.lib.vgen_dpmpp2m_sde_step(_ptr(x), _ptr(denoised), _ptr(old), _ptr(noise), float(ca), float(cb),
+                                            float(cc), float(cn), _ptr(out), x.numel(), self._stream(x))
+        _lib.check(rc, "vgen_dpmpp2m_sde_step")
+        return out
+
     def gaussian_sample(self, moments, noise, nimg, zc, HW, scale):
         assert moments.dtype == torch.float32 and moments.is_contiguous()
         assert noise.dtype == torch.float32 and noise.is_contiguous()

@@ -257,6 +257,16 @@ class UNetSD_T2VBase(nn.Module):
         # "high": every packed weight also carries its 16-bit rounding residual and the GEMMs add A . W_lo — removes the
         # largest rounding category at ~2x the tap-GEMM time; set before the first forward / pack()
         self.precision = precision or "fast"
+        if self.precision.startswith("mixed:"):
+            # "mixed:e0d01": two-term weights in encoder level 0 and decoder levels 0, 1 ("m3": the middle block at level 3)
+            import re
+            spec = self.precision.split(":", 1)[1]
+            assert re.fullmatch(r"(?:[edmt]\d*)*", spec), f"precision={self.precision!r}"
+            lv = {"e": (), "d": (), "m": (), "t": ()}
+            for side, digits in re.findall(r"([edmt])(\d*)", spec):
+                lv[side] = tuple(int(c) for c in digits)
+            self.MIXED_LEVELS = {"enc": lv["e"], "mid": lv["m"], "dec": lv["d"], "tx": lv["t"]}
+            self.precision = "mixed"
         assert self.precision in ("fast", "high", "mixed")
 
         enc_dims = [dim * u for u in [1] + list(dim_mult)]
@@ -356,7 +366,9 @@ class UNetSD_T2VBase(nn.Module):
     # resolution pass through every later block and both skip paths, errors made in the deep levels and late in the
     # decoder reach the output attenuated (per-module attribution: profiles/r03_weight_sensitivity.json,
     # tools/parity_attrib.py --by-module --set w_lin,w_conv).
-    MIXED_LEVELS = {"enc": (0, 1), "mid": (), "dec": (0, 1)}      # resolution levels (0 = full) whose blocks are split
+    # resolution levels (0 = full) whose blocks carry two-term weights: encoder / middle / decoder side, and "tx": levels
+    # where only the Spatial / TemporalTransformer blocks do (their launches are the cheap ones to run dual-W)
+    MIXED_LEVELS = {"enc": (0,), "mid": (), "dec": (0, 1), "tx": ()}
 
     def _block_levels(self):
         """top-level block name ('input_blocks.3', 'middle_block', 'output_blocks.7') -> (side, resolution level), the
@@ -393,7 +405,16 @@ class UNetSD_T2VBase(nn.Module):
         parts = name.split(".")
         top = parts[0] if parts[0] == "middle_block" else ".".join(parts[:2])
         side, level = self._block_levels().get(top, (None, None))
-        return side is not None and level in self.MIXED_LEVELS[side]
+        if side is None:
+            return False
+        if level in self.MIXED_LEVELS[side]:
+            return True
+        if level in self.MIXED_LEVELS.get("tx", ()):
+            try:
+                return isinstance(self.get_submodule(name), (_SpatialTransformerP, _TemporalTransformerP))
+            except AttributeError:
+                return False
+        return False
 
     def _pack(self, device=None):
         dt = self.compute_dtype
