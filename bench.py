@@ -462,6 +462,7 @@ def main():
                            # cross-attention, so this is a few % below the reference's 2 x forward count); a dual-W launch
                            # executes 2x the MFMA work for its product: executed_over_algorithmic says how much
                            "tapgemm_tflop_per_step": round(tot_fl / 1e12, 3),
+                           "algorithmic_bytes_per_launch": round(sum((r[5] or 0.0) for r in recs) / max(len(recs), 1)),
                            "executed_over_algorithmic": round(1.0 + sum(r[3] for r in recs if str(r[4][5]).endswith("+dw")) / max(tot_fl, 1.0), 3),
                            "measured_in_this_run": True}
         # HBM-side bytes per launch cannot be read from inside the process: they come from committed rocprofv3 PMC

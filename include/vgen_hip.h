@@ -240,6 +240,14 @@ int vgen_softmax_rows(const float* S, int64_t rows, int32_t cols, int64_t lds, f
  * purpose: inside the tap-GEMM epilogue its polynomial cost the hot UNet instantiations 55-75 spilled VGPRs. */
 int vgen_act_cast(const float* x, void* y, int64_t n, int32_t act, int32_t dtype, void* stream);
 
+/* fp32 rows -> TWO-TERM 16-bit rows: out[m, c] = hi = round16(x[m, c]), out[m, lo_off + c] = round16(x[m, c] - hi),
+ * c < C; x row stride ldx, out row stride ldo (elements).  The A-side counterpart of vgen_tapgemm_args.dualw: a GEMM
+ * over [A_hi | A_lo] against a weight repeated [W | W] computes (A_hi + A_lo) W^T — an fp32-accurate operand where the
+ * models' precision modes want one (the token stream entering SpatialTransformer / TemporalTransformer.proj_out,
+ * util.py:351,1229; the raw input of the ResBlock's 1x1 skip_connection, util.py:885,920). */
+int vgen_cast_split(const float* x, int64_t M, int32_t C, int64_t ldx, void* out, int64_t ldo, int32_t lo_off,
+                    int32_t dtype, void* stream);
+
 /* sinusoidal_embedding (util.py:178-190): out[b, :] = [cos(t_b * w_i) | sin(t_b * w_i)],
  * w_i = 10000^(-i/half); out is `dtype` (VGEN_BF16 | VGEN_F16 | VGEN_F32).  t is fp32 [B]. */
 int vgen_timestep_embedding(const float* t, int32_t B, int32_t dim, void* out, int32_t dtype,
@@ -373,6 +381,15 @@ int vgen_frame_transformer(const float* x, int64_t B, int32_t F, int32_t d, int6
  * image; mean / stdv: C device floats.  Bit-exact with the reference arithmetic (fp32, truncation). */
 int vgen_frames_u8(const float* x, int64_t rows, int32_t C, int64_t ldx, const float* mean,
                    const float* stdv, void* out, void* stream);
+
+/* Glue of a sampling session's step graph (vgen_amd/session.py), so that a captured step holds only this library's
+ * launches.  vgen_repeat_rows: dst[g*bytes .. (g+1)*bytes) = src[0 .. bytes) for g < G — the rows of the context-free
+ * prefix shared by a classifier-free-guidance pair (diffusion_ddim.py:157-158 evaluates it per branch) fanned out to
+ * the G units.  vgen_gather_rows_f32: out[r, :] = table[idx[r], :] — the time-embedding row biases of timestep t
+ * (unet_t2v.py:93-96,244-245 folded over all integer timesteps once per weight load); idx clamped to the table. */
+int vgen_repeat_rows(const void* src, int64_t bytes, int32_t G, void* dst, void* stream);
+int vgen_gather_rows_f32(const float* table, int64_t nrows_table, int64_t cols, const int64_t* idx, int64_t rows,
+                         float* out, void* stream);
 
 size_t vgen_cfg_stats_ws_bytes(int64_t B);
 int vgen_cfg_stats(const float* y, const float* u, float guide, int32_t use_guide, int64_t B,

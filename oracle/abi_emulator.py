@@ -167,6 +167,16 @@ class EmuBackend:
             return (0.5 * x * (1.0 + torch.erf(x * 0.7071067811865476))).to(dt)
         return (x * torch.sigmoid(x) if act == 1 else x).to(dt)
 
+    def cast_split(self, x, dt, out=None, col=0, lo_off=None):
+        M, Cc = x.shape
+        lo_off = Cc if lo_off is None else lo_off
+        if out is None:
+            out = torch.zeros((M, col + lo_off + Cc), dtype=dt)
+        hi = x.to(dt)
+        out[:, col: col + Cc] = hi
+        out[:, col + lo_off: col + lo_off + Cc] = (x.float() - hi.float()).to(dt)
+        return out
+
     def conv3x3_small(self, x, w, b, stride=1, act=0):
         y = torch.nn.functional.conv2d(x, w, b, stride=stride, padding=1)
         return y * torch.sigmoid(y) if act == 1 else y
@@ -331,6 +341,12 @@ class EmuBackend:
             if t is not None:
                 r = r + f(cf) * t
         return r
+
+    def repeat_rows(self, t, G):
+        return t.repeat((G,) + (1,) * (t.dim() - 1))
+
+    def gather_rows_f32(self, table, idx):
+        return table.index_select(0, idx.clamp(0, table.shape[0] - 1))
 
     def dpmpp2m_sde_step(self, x, denoised, old, noise, ca, cb, cc, cn):
         # vgen_dpmpp2m_sde_step: the three statements of diffusion_gauss.py:126-139, each rounded like a lincomb4

@@ -263,3 +263,38 @@ def test_condition_stem_kernels(hip_backend):
                                             out_scale=2.0, accumulate=True).cpu()
         ref = kc.EMU.frame_transformer(x, B, F, d, H * W, p, out=base.clone(), last=True, out_scale=2.0, accumulate=True)
         assert float((out - ref).norm() / ref.norm()) < 5e-6
+
+
+def test_step_graph_glue_kernels(hip_backend):
+    """vgen_repeat_rows / vgen_gather_rows_f32 (the copies inside a captured step): bit-equal to torch's repeat / index_select,
+    fp32 and 16-bit payloads, out-of-range indices clamped."""
+    g = torch.Generator().manual_seed(0)
+    for shape, dt in (((1792, 320), torch.float32), ((448, 640), torch.float16), ((28, 2, 320), torch.float32)):
+        t = torch.randn(shape, generator=g).to(dt).to(DEV)
+        for G in (1, 2, 3):
+            assert torch.equal(hip_backend.repeat_rows(t, G), t.repeat((G,) + (1,) * (t.dim() - 1)))
+    tab = torch.randn(1000, 20160, generator=g).to(DEV)
+    idx = torch.tensor([981, 0, 999, 981, 1005, -3], dtype=torch.long, device=DEV)
+    assert torch.equal(hip_backend.gather_rows_f32(tab, idx), tab[idx.clamp(0, 999)])
+
+
+@pytest.mark.parametrize("dtname", ["bf16", "fp16"])
+def test_cast_split_is_the_emulators_bits(hip_backend, dtname):
+    """vgen_cast_split (two-term activations): hi and lo columns bit-equal to the emulator's, hi + lo within 2^-17 (bf16) /
+    2^-22 (fp16) of the fp32 input, strided destination with a column offset (the ResBlock's two-source skip operand)."""
+    dt = kc.DTS[dtname]
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1000, 320, generator=g) * 3
+    ref = kc.EMU.cast_split(x, dt)
+    out = hip_backend.cast_split(x.to(DEV), dt)
+    assert torch.equal(out.cpu().view(torch.int16), ref.view(torch.int16))
+    rec = out[:, :320].float() + out[:, 320:].float()
+    assert float((rec.cpu() - x).abs().max() / x.abs().max()) < (2e-5 if dtname == "bf16" else 1e-6)
+    x2 = torch.randn(1000, 128, generator=g)
+    buf_ref = torch.zeros(1000, 2 * 448, dtype=dt)
+    kc.EMU.cast_split(x, dt, out=buf_ref, col=0, lo_off=448)
+    kc.EMU.cast_split(x2, dt, out=buf_ref, col=320, lo_off=448)
+    buf = torch.zeros(1000, 2 * 448, dtype=dt, device=DEV)
+    hip_backend.cast_split(x.to(DEV), dt, out=buf, col=0, lo_off=448)
+    hip_backend.cast_split(x2.to(DEV), dt, out=buf, col=320, lo_off=448)
+    assert torch.equal(buf.cpu().view(torch.int16), buf_ref.view(torch.int16))

@@ -77,7 +77,9 @@ def test_high_precision_mode_splits_every_packed_weight(emu_backend):
         hi, lo = ops.dw_terms(w.vgen_dw)
         assert torch.equal(hi, w)
     rb = mh.get_submodule(name)
-    full = torch.cat([rb.out_layers[3].weight.detach().permute(0, 2, 3, 1).reshape(rb.cout, -1), rb.skip_connection.weight.detach().reshape(rb.cout, -1)], 1)
+    wsk = rb.skip_connection.weight.detach().reshape(rb.cout, -1)
+    # out-conv | skip | skip: the skip conv's operand is a two-term pair [raw_hi | raw_lo] in this mode
+    full = torch.cat([rb.out_layers[3].weight.detach().permute(0, 2, 3, 1).reshape(rb.cout, -1), wsk, wsk], 1)
     w = P[name]["conv2"][0]
     hi, lo = ops.dw_terms(w.vgen_dw)
     assert float(((hi.float() + lo.float()) - full).abs().max() / full.abs().max()) < 2e-6

@@ -1,0 +1,26 @@
+#!/bin/bash
+# Run on the GPU box (via gpurun) from the repo root: the default bench line, rocprofv3 kernel stats of the same step
+# (eager launches, csv) and the PMC counters in SEPARATE --pmc-only passes (never combined with tracing).  Outputs under
+# gpurun_out/evidence/; tools/evidence_to_profiles.py turns them into the profiles/r03_* files.
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/evidence
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+PREC=${PREC:-mixed}
+B="python $R/bench.py --precision $PREC --no-graph --no-cpu-baseline --no-vae --no-roofline --no-e2e --no-parity --variants="
+timeout 600 python $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+tail -c 1200 $O/bench.json
+rm -rf /tmp/prof_kt
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- $B --steps 5 --warmup 2 > $O/prof_bench.json 2> /dev/null
+python $R/tools/rocprof_summary.py $(ls /tmp/prof_kt/*/*kernel_stats.csv | head -1) $O/kernel_stats_summary.csv | head -24
+SPECS=""
+for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
+  tag=$(echo $c | cut -d' ' -f1)
+  rm -rf /tmp/prof_$tag
+  timeout 400 rocprofv3 --pmc $c --output-format csv -d /tmp/prof_$tag -- $B --steps 1 --warmup 1 > /dev/null 2>&1
+  f=$(ls /tmp/prof_$tag/*/*counter_collection.csv 2>/dev/null | head -1)
+  if [ -n "$f" ]; then SPECS="$SPECS $tag=$f"; else echo "no counter file for $c"; fi
+done
+python $R/tools/pmc_classes.py $O/pmc_classes.json $SPECS | head -60
+echo EVIDENCE_DONE

@@ -7,7 +7,7 @@ layernorm, other.  Counters are summed over a dispatch's rows (one row per XCD/S
 import collections, csv, json, re, sys
 
 CLASSES = [("tapgemm", r"tapgemm_kernel"), ("splitk_reduce", r"splitk_reduce"), ("flash_attention", r"flash_kernel"),
-           ("temporal_attention", r"temporal_kernel"), ("groupnorm", r"gn_(stats|finalize|finalize_cs|apply|fused)"),
+           ("temporal_attention", r"temporal_kernel"), ("groupnorm", r"gn_(stats|finalize|finalize_cs|apply|fused|regs)"),
            ("layernorm", r"layernorm"), ("linear_f32", r"linear_f32")]
 
 

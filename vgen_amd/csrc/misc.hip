@@ -16,6 +16,23 @@ __global__ __launch_bounds__(256) void act_cast_kernel(const float* __restrict__
   y[i] = T::from_f32(v);
 }
 
+// fp32 rows -> two-term 16-bit rows: out[m, c] = hi = round16(x), out[m, lo_off + c] = round16(x - hi) (the A-side
+// counterpart of a two-term weight: [A_hi | A_lo] x [W | W]^T = (A_hi + A_lo) W^T, fp32-accurate operand)
+template <typename T>
+__global__ __launch_bounds__(256) void cast_split_kernel(const float* __restrict__ x, int64_t M, int C4, int64_t ldx,
+                                                         uint16_t* __restrict__ out, int64_t ldo, int lo_off) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= M * C4) return;
+  const int64_t m = i / C4;
+  const int c = (int)(i - m * C4) * 4;
+  const f32x4 v = *(const f32x4*)(x + m * ldx + c);
+  const u32x2 hi = pack4<T>(v.x, v.y, v.z, v.w);
+  const uint16_t* h = (const uint16_t*)&hi;
+  const u32x2 lo = pack4<T>(v.x - T::to_f32(h[0]), v.y - T::to_f32(h[1]), v.z - T::to_f32(h[2]), v.w - T::to_f32(h[3]));
+  *(u32x2*)(out + m * ldo + c) = hi;
+  *(u32x2*)(out + m * ldo + lo_off + c) = lo;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void timestep_embedding_kernel(const float* __restrict__ t, int B,
                                                                  int dim,
@@ -270,6 +287,23 @@ extern "C" int vgen_act_cast(const float* x, void* y, int64_t n, int32_t act, in
     hipLaunchKernelGGL(act_cast_kernel<F16>, dim3((unsigned)grid), dim3(256), 0, s, x,
                        (uint16_t*)y, n, act);
   return vgen_check_launch("act_cast");
+}
+
+extern "C" int vgen_cast_split(const float* x, int64_t M, int32_t C, int64_t ldx, void* out, int64_t ldo, int32_t lo_off,
+                               int32_t dtype, void* stream) {
+  VGEN_REQUIRE(dtype == VGEN_BF16 || dtype == VGEN_F16, "cast_split: dtype");
+  VGEN_REQUIRE(M >= 0 && C > 0 && C % 4 == 0 && ldx % 4 == 0 && ldo % 4 == 0 && lo_off % 4 == 0 && vgen_aligned16(x) &&
+                   ((uintptr_t)out & 7) == 0,
+               "cast_split: C / ldx / ldo / lo_off %% 4 == 0, aligned buffers");
+  if (M == 0) return 0;
+  const int64_t n = M * (C / 4), grid = (n + 255) / 256;
+  VGEN_REQUIRE(grid < (1LL << 31), "cast_split: too large");
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == VGEN_BF16)
+    hipLaunchKernelGGL(cast_split_kernel<BF16>, dim3((unsigned)grid), dim3(256), 0, s, x, M, C / 4, ldx, (uint16_t*)out, ldo, lo_off);
+  else
+    hipLaunchKernelGGL(cast_split_kernel<F16>, dim3((unsigned)grid), dim3(256), 0, s, x, M, C / 4, ldx, (uint16_t*)out, ldo, lo_off);
+  return vgen_check_launch("cast_split");
 }
 
 extern "C" int vgen_timestep_embedding(const float* t, int32_t B, int32_t dim, void* out,
@@ -561,7 +595,54 @@ __global__ __launch_bounds__(256) void dpmpp2m_sde_step_kernel(const float* __re
   out[i] = r;
 }
 
+// dst[g] = src for g < G: 16-byte lanes (the shared context-free prefix of a CFG pair fanned out to its units)
+__global__ __launch_bounds__(256) void repeat_rows_kernel(const u32x4* __restrict__ src, int64_t n16, int G,
+                                                          u32x4* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n16) return;
+  const u32x4 v = src[i];
+#pragma unroll 4
+  for (int g = 0; g < G; ++g) dst[(int64_t)g * n16 + i] = v;
+}
+
+// out[r, :] = table[idx[r], :] (fp32 rows; the per-timestep row biases of a sampling session)
+__global__ __launch_bounds__(256) void gather_rows_f32_kernel(const float* __restrict__ table, const int64_t* __restrict__ idx,
+                                                              int64_t rows, int64_t cols4, int64_t nrows_table,
+                                                              float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows * cols4) return;
+  const int64_t r = i / cols4, c = i - r * cols4;
+  int64_t t = idx[r];
+  t = t < 0 ? 0 : (t >= nrows_table ? nrows_table - 1 : t);
+  ((f32x4*)out)[i] = ((const f32x4*)table)[t * cols4 + c];
+}
+
 }  // namespace
+
+extern "C" int vgen_repeat_rows(const void* src, int64_t bytes, int32_t G, void* dst, void* stream) {
+  VGEN_REQUIRE(src != nullptr && dst != nullptr && G >= 1 && bytes >= 0 && bytes % 16 == 0 && vgen_aligned16(src) &&
+                   vgen_aligned16(dst),
+               "repeat_rows: 16-byte aligned buffers, bytes %% 16 == 0");
+  if (bytes == 0) return 0;
+  const int64_t n16 = bytes / 16, grid = (n16 + 255) / 256;
+  VGEN_REQUIRE(grid < (1LL << 31), "repeat_rows: too large");
+  hipLaunchKernelGGL(repeat_rows_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, (const u32x4*)src, n16,
+                     G, (u32x4*)dst);
+  return vgen_check_launch("repeat_rows");
+}
+
+extern "C" int vgen_gather_rows_f32(const float* table, int64_t nrows_table, int64_t cols, const int64_t* idx,
+                                    int64_t rows, float* out, void* stream) {
+  VGEN_REQUIRE(table != nullptr && idx != nullptr && out != nullptr && cols > 0 && cols % 4 == 0 && nrows_table > 0 &&
+                   vgen_aligned16(table) && vgen_aligned16(out),
+               "gather_rows_f32: cols %% 4 == 0, aligned buffers");
+  if (rows <= 0) return 0;
+  const int64_t n = rows * (cols / 4), grid = (n + 255) / 256;
+  VGEN_REQUIRE(grid < (1LL << 31), "gather_rows_f32: too large");
+  hipLaunchKernelGGL(gather_rows_f32_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, table, idx, rows,
+                     cols / 4, nrows_table, out);
+  return vgen_check_launch("gather_rows_f32");
+}
 
 extern "C" int vgen_dpmpp2m_sde_step(const float* x, const float* denoised, const float* old_denoised, const float* noise,
                                      float ca, float cb, float cc, float cn, float* out, int64_t n, void* stream) {

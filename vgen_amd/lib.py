@@ -73,6 +73,7 @@ SYMBOLS = {
     "vgen_attention": (C.c_int, [C.POINTER(AttnArgs), _vp]),
     "vgen_softmax_rows": (C.c_int, [_vp, _i64, _i32, _i64, _f32, _vp, _i64, _i32, _vp]),
     "vgen_act_cast": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "vgen_cast_split": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _i32, _i32, _vp]),
     "vgen_timestep_embedding": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp]),
     "vgen_conv3x3_small": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "vgen_adaptive_avgpool2d": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
@@ -97,6 +98,8 @@ SYMBOLS = {
     "vgen_cfg_stats": (C.c_int, [_vp, _vp, _f32, _i32, _i64, _i64, _vp, _vp, _sz, _vp]),
     "vgen_gauss_x0": (C.c_int, [_vp, _vp, _vp, _f32, _vp, _i32, _i64, _i64, _vp, _vp, _vp]),
     "vgen_lincomb4": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _i64, _vp]),
+    "vgen_repeat_rows": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
+    "vgen_gather_rows_f32": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp]),
     "vgen_dpmpp2m_sde_step": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _i64, _vp]),
 }
 

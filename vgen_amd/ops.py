@@ -156,9 +156,9 @@ class HipBackend:
 
     class _Prof:
         """Brackets a launch with HIP events on the launch stream when KERNEL_PROFILE is a list."""
-        def __init__(self, name, work, meta):
+        def __init__(self, name, work, meta, extra=None):
             self.rec = KERNEL_PROFILE
-            self.name, self.work, self.meta = name, work, meta
+            self.name, self.work, self.meta, self.extra = name, work, meta, extra
 
         def __enter__(self):
             if self.rec is not None:
@@ -170,7 +170,7 @@ class HipBackend:
         def __exit__(self, *exc):
             if self.rec is not None:
                 self.e1.record()
-                self.rec.append((self.name, self.e0, self.e1, self.work, self.meta))
+                self.rec.append((self.name, self.e0, self.e1, self.work, self.meta, self.extra))
             return False
 
     # -- norms -----------------------------------------------------------------------------
@@ -266,7 +266,12 @@ class HipBackend:
             flags = (1 if g.residual is not None else 0) | (2 if g.rowbias is not None else 0) | (4 if cs is not None else 0)
             meta = meta + ((g.mode, g.M, g.N, g.C1, g.C2, g.taps, g.epilogue, _ENUM[g.out_dtype], flags), tuple(pl))
         # algorithmic FLOP: the product A . W^T (a dual-W launch executes twice the MFMAs for the same product)
-        with self._Prof("tapgemm", 2.0 * g.M * g.N * K, meta):
+        # algorithmic HBM bytes: every distinct operand element once (A's source rows, both weight terms, output, fp32
+        # residual) — what a launch must move if nothing were re-read
+        src_rows = A.shape[0] if g.mode != _lib.TAP_LINEAR else g.M
+        abytes = (2.0 * src_rows * g.C1 + 2.0 * g.M * g.C2 + 2.0 * g.N * K * (2 if dw is not None else 1) +
+                  float(g.M) * n_out * ((4 if g.out_dtype == torch.float32 else 2) + (4 if g.residual is not None else 0)))
+        with self._Prof("tapgemm", 2.0 * g.M * g.N * K, meta, abytes):
             rc = self.lib.vgen_tapgemm(C.byref(a), self._stream(A))
         _lib.check(rc, "vgen_tapgemm")
         if cs is not None:
@@ -310,6 +315,21 @@ class HipBackend:
             rc = self.lib.vgen_act_cast(_ptr(x), _ptr(y), x.numel(), int(act), _ENUM[dt], self._stream(x))
         _lib.check(rc, "vgen_act_cast")
         return y
+
+    def cast_split(self, x, dt, out=None, col=0, lo_off=None):
+        """fp32 [M, C] -> two-term 16-bit rows (vgen_cast_split): out[:, col : col + C] = hi, out[:, col + lo_off : ...] =
+        lo; default out = new [M, 2 C] = [hi | lo]."""
+        assert x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1
+        M, Cc = x.shape
+        lo_off = Cc if lo_off is None else lo_off
+        if out is None:
+            out = torch.empty((M, col + lo_off + Cc), dtype=dt, device=x.device)
+        _mat(out, "out")
+        assert out.dtype == dt and out.shape[0] == M and out.shape[1] >= col + lo_off + Cc
+        rc = self.lib.vgen_cast_split(_ptr(x), M, Cc, x.stride(0), C.c_void_p(out.data_ptr() + 2 * col), out.stride(0),
+                                      int(lo_off), _ENUM[dt], self._stream(x))
+        _lib.check(rc, "vgen_cast_split")
+        return out
 
     # -- condition stems (fp32, NCHW frames; once per sampling session) ------------------------------------
     def conv3x3_small(self, x, w, b, stride=1, act=0):
@@ -486,6 +506,24 @@ class HipBackend:
         rc = self.lib.vgen_lincomb4(_ptr(a), _ptr(b), _ptr(c), _ptr(d), float(ca), float(cb), float(cc), float(cd),
                                     _ptr(out), a.numel(), self._stream(a))
         _lib.check(rc, "vgen_lincomb4")
+        return out
+
+    def repeat_rows(self, t, G):
+        """[rows, ...] -> [G * rows, ...], G copies stacked along dim 0 (vgen_repeat_rows)."""
+        assert t.is_contiguous() and (t.numel() * t.element_size()) % 16 == 0
+        out = torch.empty((G * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        rc = self.lib.vgen_repeat_rows(_ptr(t), t.numel() * t.element_size(), int(G), _ptr(out), self._stream(t))
+        _lib.check(rc, "vgen_repeat_rows")
+        return out
+
+    def gather_rows_f32(self, table, idx):
+        """table[idx] for a 2-D fp32 table and int64 row indices (vgen_gather_rows_f32)."""
+        assert table.dtype == torch.float32 and table.is_contiguous() and table.dim() == 2
+        assert idx.dtype == torch.int64 and idx.is_contiguous() and idx.dim() == 1
+        out = torch.empty((idx.shape[0], table.shape[1]), dtype=torch.float32, device=table.device)
+        rc = self.lib.vgen_gather_rows_f32(_ptr(table), table.shape[0], table.shape[1], _ptr(idx), idx.shape[0],
+                                           _ptr(out), self._stream(table))
+        _lib.check(rc, "vgen_gather_rows_f32")
         return out
 
     def dpmpp2m_sde_step(self, x, denoised, old, noise, ca, cb, cc, cn):

@@ -109,7 +109,7 @@ class UnitSession:
         self.out = torch.empty((nU, model.out_dim, self.F, self.H, self.W), dtype=torch.float32, device=self.device)
         # time-embedding table: integer timesteps of a known schedule length, no fps term inside the SiLU
         self.emb_tab = None
-        if num_timesteps and not t_dtype.is_floating_point and self.fps is None:
+        if num_timesteps and t_dtype == torch.long and self.fps is None:
             self.emb_tab = model.time_embedding_table(int(num_timesteps), self.device)
         self.use_graph = _GRAPH_ON and self.device.type == "cuda"
         # every graph of this session (model-only, DDIM kinds / strides / etas, ...) captures into ONE private memory
@@ -144,7 +144,7 @@ class UnitSession:
         m = self.model
         nU = len(self.units)
         if self.emb_tab is not None:
-            emb = self.emb_tab.index_select(0, self.t_units)
+            emb = ops.backend().gather_rows_f32(self.emb_tab, self.t_units)
         else:
             emb = m._embed(self.t_units, self.fps, nU, self.device)
         m._body(self.x_units, emb, self.kv, self.Lctx, self.per_frame, out=self.out, shared_groups=self.shared)

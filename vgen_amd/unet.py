@@ -268,6 +268,11 @@ class UNetSD_T2VBase(nn.Module):
             self.MIXED_LEVELS = {"enc": lv["e"], "mid": lv["m"], "dec": lv["d"], "tx": lv["t"]}
             self.precision = "mixed"
         assert self.precision in ("fast", "high", "mixed")
+        # two-term ACTIVATIONS at the two places where a plain fp32 -> 16-bit cast of a residual-stream tensor is a GEMM
+        # operand (attribution, DESIGN §4.1: 0.157 + 0.126 of the 0.758e-6 error energy left once the weights are exact):
+        # the raw input of the ResBlock's 1x1 skip conv and the token stream entering proj_out.  On in every mode but
+        # "fast"; K of those two (small) segments doubles: [A_hi | A_lo] x [W | W]^T.
+        self._asplit = self.precision != "fast"
 
         enc_dims = [dim * u for u in [1] + list(dim_mult)]
         dec_dims = [dim * u for u in [dim_mult[-1]] + list(dim_mult)[::-1]]
@@ -368,7 +373,7 @@ class UNetSD_T2VBase(nn.Module):
     # tools/parity_attrib.py --by-module --set w_lin,w_conv).
     # resolution levels (0 = full) whose blocks carry two-term weights: encoder / middle / decoder side, and "tx": levels
     # where only the Spatial / TemporalTransformer blocks do (their launches are the cheap ones to run dual-W)
-    MIXED_LEVELS = {"enc": (0,), "mid": (), "dec": (0, 1), "tx": ()}
+    MIXED_LEVELS = {"enc": (0,), "mid": (), "dec": (0,), "tx": ()}
 
     def _block_levels(self):
         """top-level block name ('input_blocks.3', 'middle_block', 'output_blocks.7') -> (side, resolution level), the
@@ -464,7 +469,9 @@ class UNetSD_T2VBase(nn.Module):
             d["gn2"] = (_f32(rb.out_layers[0].weight), _f32(rb.out_layers[0].bias))
             b2 = _f32(rb.out_layers[3].bias)
             if isinstance(rb.skip_connection, nn.Conv2d):
-                w2 = _w16_cat([pack_conv3x3(rb.out_layers[3].weight), pack_linear(rb.skip_connection.weight)], dt)
+                wsk = pack_linear(rb.skip_connection.weight)
+                # two-term skip operand [raw_hi | raw_lo]: the 1x1 weight appears twice
+                w2 = _w16_cat([pack_conv3x3(rb.out_layers[3].weight), wsk] + ([wsk] if self._asplit else []), dt)
                 b2 = (b2 + _f32(rb.skip_connection.bias)).contiguous()
             else:
                 w2 = pack_conv3x3(rb.out_layers[3].weight, dt)
@@ -497,7 +504,10 @@ class UNetSD_T2VBase(nn.Module):
         def pack_tx(m, cross):
             d = {"gn": (_f32(m.norm.weight), _f32(m.norm.bias))}
             d["pin"] = (pack_linear(m.proj_in.weight, dt), _f32(m.proj_in.bias))
-            d["pout"] = (pack_linear(m.proj_out.weight, dt), _f32(m.proj_out.bias))
+            wpo = pack_linear(m.proj_out.weight)
+            if self._asplit:                      # two-term token stream [t_hi | t_lo]: the weight appears twice
+                wpo = torch.cat([wpo, wpo], 1)
+            d["pout"] = (_w16(wpo, dt), _f32(m.proj_out.bias))
             d["tb"] = pack_tblock(m.transformer_blocks[0], cross)
             return d
 
@@ -547,7 +557,15 @@ class UNetSD_T2VBase(nn.Module):
         S = H * W
         M = B * F * S
         has_skip = isinstance(rb.skip_connection, nn.Conv2d)
-        a1, raw = be.groupnorm(x1, x2, B * F, S, 32, 1e-5, *P["gn1"], True, has_skip, dt)
+        a1, raw = be.groupnorm(x1, x2, B * F, S, 32, 1e-5, *P["gn1"], True, has_skip and not self._asplit, dt)
+        c2 = rb.cin
+        if has_skip and self._asplit:
+            # the skip conv's operand as a two-term pair [hi(x1) hi(x2) | lo(x1) lo(x2)] (x = the virtual concat)
+            raw = torch.empty((M, 2 * rb.cin), dtype=dt, device=x1.device)
+            be.cast_split(x1, dt, out=raw, col=0, lo_off=rb.cin)
+            if x2 is not None:
+                be.cast_split(x2, dt, out=raw, col=x1.shape[1], lo_off=rb.cin)
+            c2 = 2 * rb.cin
         rowbias = emb_all[:, rb._emb_off: rb._emb_off + rb.cout]
         # colstats=True: the conv epilogue leaves per-slab column sums behind, so the GroupNorm that
         # consumes this tensor skips its statistics pass (every GN input of the UNet is a tap-GEMM output)
@@ -555,7 +573,7 @@ class UNetSD_T2VBase(nn.Module):
                                 colstats=True)
         a2, _ = be.groupnorm(h, None, B * F, S, 32, 1e-5, *P["gn2"], True, False, dt)
         if has_skip:
-            h, _, _ = self._conv3x3(a2, P["conv2"], B * F, H, W, rb.cout, A2=raw, C2=rb.cin, colstats=True)
+            h, _, _ = self._conv3x3(a2, P["conv2"], B * F, H, W, rb.cout, A2=raw, C2=c2, colstats=True)
         else:
             assert x2 is None
             h, _, _ = self._conv3x3(a2, P["conv2"], B * F, H, W, rb.cout, residual=x1, colstats=True)
@@ -582,8 +600,14 @@ class UNetSD_T2VBase(nn.Module):
         x = self._linear(o, P["o2"], M, residual=x)
         n = be.layernorm(x, *P["ln3"], 1e-5, dt)
         g = self._linear(n, P["ff1"], M, out_dtype=dt, epilogue=L.EPI_GEGLU)
-        # FF output is only consumed by proj_out -> emit it 16-bit (sum formed in fp32)
-        return self._linear(g, P["ff2"], M, residual=x, out_dtype=dt)
+        return self._ff_out(g, P["ff2"], M, x)
+
+    def _ff_out(self, g, ff2, M, tok):
+        """tok + FF-out, as the A operand of proj_out: emitted 16-bit straight from the GEMM (sum formed in fp32), or — with
+        two-term activations — fp32 and split into [hi | lo] columns (proj_out's weight is packed twice)."""
+        if not self._asplit:
+            return self._linear(g, ff2, M, residual=tok, out_dtype=self.compute_dtype)
+        return ops.backend().cast_split(self._linear(g, ff2, M, residual=tok), self.compute_dtype)
 
     def _spatial_tx(self, st: _SpatialTransformerP, x, kv_all, B, F, H, W, Lctx, kv_per_frame=False, share=1,
                     replicate=None):
@@ -617,7 +641,7 @@ class UNetSD_T2VBase(nn.Module):
         n = be.layernorm(tok, *T["ln2"], 1e-5, dt)
         q = self._linear(n, T["q2"], Mp, out_dtype=dt)
         if share > 1:
-            tok, q, x = replicate(tok), q.repeat(share, 1), replicate(x)
+            tok, q, x = replicate(tok), be.repeat_rows(q, share), replicate(x)
         o = torch.empty((M, d), dtype=dt, device=q.device)
         kw = kv_all.shape[1]
         k = kv_all[:, st._kv_off: st._kv_off + d]
@@ -631,7 +655,7 @@ class UNetSD_T2VBase(nn.Module):
         # x = x + ff(norm3(x)); the FF output is only consumed by proj_out -> emitted 16-bit (sum formed in fp32)
         n = be.layernorm(tok, *T["ln3"], 1e-5, dt)
         g = self._linear(n, T["ff1"], M, out_dtype=dt, epilogue=L.EPI_GEGLU)
-        t = self._linear(g, T["ff2"], M, residual=tok, out_dtype=dt)
+        t = self._ff_out(g, T["ff2"], M, tok)
         return self._linear(t, P["pout"], M, residual=x, colstats=True)
 
     def _temporal_tx(self, tt: _TemporalTransformerP, x, B, F, H, W):
@@ -827,10 +851,10 @@ class UNetSD_T2VBase(nn.Module):
             """rows of the Bp shared units -> rows of all B units (group-major), producer statistics included"""
             if G == 1:
                 return t
-            r = t.repeat(G, 1)
+            r = be.repeat_rows(t, G)
             cs = ops.colstats_of(t, t.shape[0])
             if cs is not None and t.shape[0] % ops.CS_ROWS == 0:
-                r.vgen_cs = cs.repeat(G, 1, 1)
+                r.vgen_cs = be.repeat_rows(cs, G)
             return r
 
         xs = []

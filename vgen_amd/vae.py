@@ -379,6 +379,33 @@ class AutoencoderKL(nn.Module):
             return o.view(B, F, *o.shape[1:])
         return o.view(B, F, *o.shape[1:]).permute(0, 2, 1, 3, 4)
 
+    def to_host_async(self, frames, slot=0):
+        """Hand decoded frames to the host-side writer without stalling the GPU queue (f3; consumer:
+        utils/video_op.py:181-213, which today receives `video.cpu()` — a synchronous 22 MB fp32 copy per video,
+        inference_text2video_entrance.py:225): `frames` (the uint8 [B, F, H, W, 3] of decode_video: 5.5 MB) is copied
+        into a reused PINNED host buffer on a side stream that first waits for the compute stream; returns (host tensor,
+        event).  The next prompt's sampling is enqueued immediately; the writer calls `event.synchronize()` before it
+        reads.  `slot` selects one of the reusable pinned buffers (two prompts in flight: slots 0 / 1)."""
+        if not frames.is_cuda:
+            return frames, None
+        key = (slot, tuple(frames.shape), frames.dtype)
+        bufs = self.__dict__.setdefault("_pinned", {})
+        host = bufs.get(key)
+        if host is None:
+            host = torch.empty(frames.shape, dtype=frames.dtype, pin_memory=True)
+            bufs[key] = host
+        side = self.__dict__.get("_copy_stream")
+        if side is None:
+            side = torch.cuda.Stream(device=frames.device)
+            self.__dict__["_copy_stream"] = side
+        side.wait_stream(torch.cuda.current_stream(frames.device))
+        with torch.cuda.stream(side):
+            host.copy_(frames, non_blocking=True)
+            frames.record_stream(side)
+            ev = torch.cuda.Event()
+            ev.record(side)
+        return host, ev
+
     @torch.no_grad()
     def _decode_rows(self, z):
         """-> (decoder output rows [n*H*W, out_ch] fp32, n, H, W)"""
