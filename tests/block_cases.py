@@ -12,7 +12,7 @@ def run_blocks(dtname, dev):
     from vgen_amd import ops
     from vgen_amd.unet import UNetSD_T2VBase, _ResBlockP, _SpatialTransformerP, _TemporalTransformerP, _DownP, _UpP
     g0, g = gold("unet_tiny.pt"), gold("unet_blocks_tiny.pt")
-    m = UNetSD_T2VBase(**g0["cfg"], compute_dtype=dtname).eval()
+    m = UNetSD_T2VBase(**g0["cfg"], compute_dtype=dtname, precision="fast").eval()
     m.load_state_dict(torch_ref.synth_state_dict(g0["shapes"], seed=g0["seed"]), strict=True)
     m = m.to(dev)
     m.pack()

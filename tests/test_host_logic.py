@@ -13,7 +13,7 @@ def _unet(dtname="fp16"):
     from vgen_amd.unet import UNetSD_T2VBase
     g = gold("unet_tiny.pt")
     sd = torch_ref.synth_state_dict(g["shapes"], seed=g["seed"])
-    m = UNetSD_T2VBase(**g["cfg"], compute_dtype=dtname).eval()
+    m = UNetSD_T2VBase(**g["cfg"], compute_dtype=dtname, precision="fast").eval()
     m.load_state_dict(sd, strict=True)
     return m, g, sd
 
@@ -332,7 +332,7 @@ def test_sr600_oracle_and_host_logic_vs_reference_golden(emu_backend):
     g = gold("unet_sr600_tiny.pt")
     sd = torch_ref.synth_state_dict(g["shapes"], seed=g["seed"])
     assert rel_l2(torch_ref.unet_sr600_forward(sd, g["x"], g["t"], g["y"], g["cfg"]["dim"]), g["out"]) < 2e-5
-    m = UNetSD_SR600(**g["cfg"], compute_dtype="fp16").eval()
+    m = UNetSD_SR600(**g["cfg"], compute_dtype="fp16", precision="fast").eval()
     assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v) for k, v in g["shapes"].items()}
     m.load_state_dict(sd, strict=True)
     out = m(g["x"], g["t"], g["y"], x_lr=None)
@@ -347,7 +347,7 @@ def test_i2vgen_oracle_and_host_logic_vs_reference_golden(emu_backend):
     ref = torch_ref.unet_i2vgen_forward(sd, g["x"], g["t"], g["y"], g["image"], g["local_image"], g["fps"],
                                         g["cfg"]["dim"])
     assert rel_l2(ref, g["out"]) < 2e-5                      # the restatement is pinned to the reference's output
-    m = UNetSD_I2VGen(**g["cfg"], compute_dtype="fp16").eval()
+    m = UNetSD_I2VGen(**g["cfg"], compute_dtype="fp16", precision="fast").eval()
     assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v) for k, v in g["shapes"].items()}
     m.load_state_dict(sd, strict=True)
     kw = dict(y=g["y"], image=g["image"], local_image=g["local_image"], fps=g["fps"])
@@ -400,7 +400,7 @@ def test_videolcm_text_oracle_and_host_logic_vs_reference_golden(emu_backend):
     ref = torch_ref.unet_videolcm_text_forward(sd, g["x"], g["t"], g["y"], g["cfg"]["dim"], g["cfg"]["concat_dim"])
     assert rel_l2(ref, g["out"]) < 2e-5
     cfg = types.SimpleNamespace(video_compositions=["text"], resolution=[64, 128])
-    m = UNetSD_VideoLCM(config=cfg, **g["cfg"], compute_dtype="fp16").eval()
+    m = UNetSD_VideoLCM(config=cfg, **g["cfg"], compute_dtype="fp16", precision="fast").eval()
     assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v) for k, v in g["shapes"].items()}
     m.load_state_dict(sd, strict=True)
     out = m(g["x"], g["t"], y=g["y"])                       # float timesteps, like the LCM engine
@@ -421,7 +421,7 @@ def test_tft2v_text_image_oracle_and_host_logic_vs_reference_golden(emu_backend)
                                                image=g["image"])
     assert rel_l2(ref, g["out"]) < 2e-5
     cfg = types.SimpleNamespace(video_compositions=["text", "image"], resolution=[64, 128])
-    m = UNetSD_TFT2V(config=cfg, **g["cfg"], compute_dtype="fp16").eval()
+    m = UNetSD_TFT2V(config=cfg, **g["cfg"], compute_dtype="fp16", precision="fast").eval()
     assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v) for k, v in g["shapes"].items()}
     m.load_state_dict(sd, strict=True)
     out = m(g["x"], g["t"], y=g["y"], image=g["image"])
@@ -445,7 +445,7 @@ def test_vcomposer_spatial_stems_oracle_and_host_logic_vs_reference_golden(emu_b
     assert rel_l2(ref, g["out"]) < 2e-5
     cfg = types.SimpleNamespace(video_compositions=g["comps"], resolution=g["resolution"])
     for cls in (UNetSD_TFT2V, UNetSD_VideoLCM):            # same trunk, same parameter set
-        m = cls(config=cfg, **g["cfg"], compute_dtype="fp16").eval()
+        m = cls(config=cfg, **g["cfg"], compute_dtype="fp16", precision="fast").eval()
         assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v) for k, v in g["shapes"].items()}
     m.load_state_dict(sd, strict=True)
     out = m(g["x"], g["t"], y=g["y"], image=g["image"], **conds)
@@ -479,7 +479,7 @@ def test_histogram_per_frame_context_oracle_and_host_logic_vs_reference_golden(e
                                           g["resolution"], histogram=g["histogram"], canny=canny)
     assert rel_l2(ref, g["out"]) < 2e-5
     cfg = types.SimpleNamespace(video_compositions=g["comps"], resolution=g["resolution"])
-    m = UNetSD_VideoLCM(config=cfg, **g["cfg"], compute_dtype="fp16").eval()
+    m = UNetSD_VideoLCM(config=cfg, **g["cfg"], compute_dtype="fp16", precision="fast").eval()
     assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == {k: tuple(v) for k, v in g["shapes"].items()}
     m.load_state_dict(sd, strict=True)
     out = m(g["x"], g["t"], y=g["y"], histogram=g["histogram"], canny=canny)

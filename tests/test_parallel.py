@@ -66,7 +66,7 @@ def _unet_case(P):
     from oracle import torch_ref
     from vgen_amd.unet import UNetSD_T2VBase
     g = gold("unet_tiny.pt")
-    m = UNetSD_T2VBase(**g["cfg"], compute_dtype="fp16").eval()
+    m = UNetSD_T2VBase(**g["cfg"], compute_dtype="fp16", precision="fast").eval()
     m.load_state_dict(torch_ref.synth_state_dict(g["shapes"], seed=g["seed"]), strict=True)
     gen = torch.Generator().manual_seed(3)
     noise = torch.randn(P, 4, 2, 8, 8, generator=gen)

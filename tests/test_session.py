@@ -14,7 +14,7 @@ def _unet(dtname="fp16"):
     from vgen_amd.unet import UNetSD_T2VBase
     g = gold("unet_tiny.pt")
     sd = torch_ref.synth_state_dict(g["shapes"], seed=g["seed"])
-    m = UNetSD_T2VBase(**g["cfg"], compute_dtype=dtname).eval()
+    m = UNetSD_T2VBase(**g["cfg"], compute_dtype=dtname, precision="fast").eval()
     m.load_state_dict(sd, strict=True)
     return m, g, sd
 
@@ -90,7 +90,7 @@ def test_partition_passes_every_per_unit_kwarg(emu_backend):
     g = gold("unet_tft2v_tiny.pt")
     sd = torch_ref.synth_state_dict(g["shapes"], seed=g["seed"])
     cfg = types.SimpleNamespace(video_compositions=["text", "image"], resolution=[64, 128])
-    m = UNetSD_TFT2V(config=cfg, **g["cfg"], compute_dtype="fp16").eval()
+    m = UNetSD_TFT2V(config=cfg, **g["cfg"], compute_dtype="fp16", precision="fast").eval()
     m.load_state_dict(sd, strict=True)
     B = g["x"].shape[0]
     kw = [dict(y=g["y"], image=g["image"], fps=torch.full((B,), 8)),

@@ -163,7 +163,7 @@ def build(full, dtname):
     from vgen_amd.unet import UNetSD_T2VBase
     g = gold("unet_t2v_full.pt" if full else "unet_tiny.pt")
     sd = torch_ref.synth_state_dict(g["shapes"], seed=g["seed"])
-    m = UNetSD_T2VBase(**g["cfg"], compute_dtype=dtname).eval()
+    m = UNetSD_T2VBase(**g["cfg"], compute_dtype=dtname, precision="fast").eval()
     m.load_state_dict(sd, strict=True)
     del sd
     if full:

@@ -13,7 +13,7 @@ from vgen_amd.session import UnitSession
 DEV = "cuda:0"
 g = gold("unet_tiny.pt")
 sd = torch_ref.synth_state_dict(g["shapes"], seed=g["seed"])
-m = UNetSD_T2VBase(**g["cfg"], compute_dtype="bf16").eval()
+m = UNetSD_T2VBase(**g["cfg"], compute_dtype="bf16", precision="fast").eval()
 m.load_state_dict(sd, strict=True)
 m = m.to(DEV)
 x, y = g["x"].to(DEV), g["y"].to(DEV)
