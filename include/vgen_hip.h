@@ -58,14 +58,16 @@ const char* vgen_last_error(void);
  * C % groups == 0 are required; C <= 3072.
  * y   : [nb*S, C] 16-bit, = act(gamma * (x - mean) * rstd + beta), act = SiLU if silu != 0
  * raw : optional [nb*S, C] 16-bit plain cast of the concatenated input (feeds the 1x1
- *       skip_connection conv, util.py:885); NULL to skip.
+ *       skip_connection conv, util.py:885); NULL to skip.  raw_split != 0: two-term rows
+ *       [nb*S, 2C] = [hi | lo], lo = round16(x - hi) (the models' two-term-activation modes;
+ *       the skip conv's weight is then packed twice, see vgen_cast_split).
  * ws  : fp32 scratch, at least vgen_groupnorm_ws_bytes(nb, S) bytes.
  */
 size_t vgen_groupnorm_ws_bytes(int64_t nb, int64_t S);
 int vgen_groupnorm(const float* x1, int32_t C1, const float* x2, int32_t C2,
                    int64_t nb, int64_t S, int32_t groups, float eps,
                    const float* gamma, const float* beta, int32_t silu,
-                   void* y, void* raw, int32_t dtype,
+                   void* y, void* raw, int32_t raw_split, int32_t dtype,
                    float* ws, size_t ws_bytes, void* stream);
 
 /* Same operator when the producer of x1 / x2 already left per-column statistics behind
@@ -78,7 +80,7 @@ int vgen_groupnorm_cs(const float* x1, int32_t C1, const float* cs1,
                       const float* x2, int32_t C2, const float* cs2,
                       int64_t nb, int64_t S, int32_t groups, float eps,
                       const float* gamma, const float* beta, int32_t silu,
-                      void* y, void* raw, int32_t dtype,
+                      void* y, void* raw, int32_t raw_split, int32_t dtype,
                       float* ws, size_t ws_bytes, void* stream);
 
 /* Token + positional embedding of the CLIP text tower (tools/modules/clip_embedder.py:155-156):
@@ -175,6 +177,11 @@ typedef struct vgen_tapgemm_args {
                       K-tile staged once — the models' precision="high" mode (packed 16-bit weights are the largest
                       rounding in the UNet; with them as hi + lo pairs its output is within 1e-3 of the reference's
                       fp32 forward, tools/modules/unet/unet_t2v.py:210-277).  K <= 65504.  0: W is [N, K]. */
+  int32_t split_out; /* 1: 16-bit output as TWO-TERM rows: out[m, n] = hi = round16(v), out[m, N + n] = round16(v - hi)
+                      (row stride ldo >= 2 N) — what vgen_cast_split would make of the fp32 value, without the fp32
+                      round trip.  The FF output + token stream that SpatialTransformer / TemporalTransformer.proj_out
+                      consume (util.py:351,1229,737) in the models' two-term-activation modes.  Needs out_dtype 16-bit,
+                      no GEGLU / colstats, N % 32 == 0, ldo % 8 == 0; never split along K. */
 } vgen_tapgemm_args;
 
 /* Launches whose tile count cannot fill the 256 CUs (small M: the 4x7 / 8x14 UNet levels) are

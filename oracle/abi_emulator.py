@@ -49,7 +49,13 @@ class EmuBackend:
         y = ((v - mean) / torch.sqrt(var + eps)).view(nb * S, C) * gamma + beta
         if silu:
             y = y * torch.sigmoid(y)
-        return y.to(dt), (x.to(dt) if want_raw else None)
+        raw = None
+        if want_raw == "split":                          # two-term rows [hi | lo] (vgen_groupnorm raw_split)
+            hi = x.to(dt)
+            raw = torch.cat([hi, (x.float() - hi.float()).to(dt)], 1)
+        elif want_raw:
+            raw = x.to(dt)
+        return y.to(dt), raw
 
     def layernorm(self, x, gamma, beta, eps, dt):
         mean = x.mean(-1, keepdim=True)
@@ -122,10 +128,14 @@ class EmuBackend:
         if g.residual is not None:
             acc += g.residual[:, :n_out]
         out = g.out
+        split = bool(getattr(g, "split_out", False))
         if out is None:
-            out = torch.empty((g.M, n_out), dtype=g.out_dtype)
+            out = torch.empty((g.M, 2 * n_out if split else n_out), dtype=g.out_dtype)
         assert out.dtype == g.out_dtype and out.dtype in (torch.float32, dt)
         out[:, :n_out] = acc.to(g.out_dtype)
+        if split:                                           # two-term rows: [round16(v) | round16(v - hi)]
+            assert g.out_dtype == dt and g.epilogue == L.EPI_NONE and not g.colstats
+            out[:, n_out: 2 * n_out] = (acc - out[:, :n_out].float()).to(dt)
         if g.colstats:
             assert g.out_dtype == torch.float32 and g.epilogue == L.EPI_NONE and g.N % 4 == 0
             ns = (g.M + 63) // 64

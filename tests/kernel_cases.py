@@ -293,6 +293,9 @@ GN_CASES = [  # nb, S, C1, C2, silu, raw
     (16, 128, 320, 0, True, False), (2, 96, 1280, 640, True, True), (1, 256, 64, 0, False, False),
     (3, 50, 128, 0, True, False), (1, 37, 2560, 0, True, False), (2, 1792, 320, 0, True, False),
     (2, 33, 640, 320, True, True),
+    # two-term raw copy [hi | lo] (vgen_groupnorm raw_split): single-launch LDS kernel, register-resident kernel, streaming pass
+    (2, 96, 1280, 640, True, "split"), (2, 448, 1280, 1280, True, "split"), (3, 1001, 640, 640, True, "split"),
+    (2, 12000, 320, 0, True, "split"),
     # group slice > 64 KiB: the three-launch streaming path (smaller slices take the single-launch kernel)
     (2, 1792, 1280, 0, True, False), (3, 1001, 640, 640, True, True), (2, 12000, 320, 0, True, False),
     # single-launch kernel: slice just under the LDS bound, two-source rows, odd row counts
@@ -350,6 +353,8 @@ def tapgemm_cases(dt):
     c["cs_lin_wide_dual"] = make_tapgemm(dt, 9000, 1280, 128, colstats=True)
     c["temporal_b128"] = make_tapgemm(dt, 1 * 16 * 28, 128, 128, mode=L.TAP_TEMPORAL3, F=16, S=28)
     c["lin_154x4096x1024_textmlp"] = make_tapgemm(dt, 154, 4096, 1024)
+    c["lin_ff2_split_out_640"] = make_tapgemm(dt, 3000, 640, 2560, out_dtype=dt, residual=True, split_out=True)
+    c["lin_split_out_shortK_dual"] = make_tapgemm(dt, 9000, 320, 320, out_dtype=dt, residual=True, split_out=True)
     return c
 
 
@@ -387,6 +392,9 @@ def tapgemm_dw_cases(dt):
                                        colstats=True, dualw=True)
     c["dw_temporal_splitk"] = make_tapgemm(dt, 2 * 4 * 28, 640, 640, mode=L.TAP_TEMPORAL3, F=4, S=28, residual=True, dualw=True)
     c["dw_lin_splitk_out16"] = make_tapgemm(dt, 300, 256, 2048, out_dtype=dt, dualw=True)
+    # two-term OUTPUT rows [hi | lo] (the FF output feeding proj_out): 160- and 128-wide column tiles, ragged M
+    c["dw_ff2_split_out_320"] = make_tapgemm(dt, 4000, 320, 1280, out_dtype=dt, residual=True, split_out=True, dualw=True)
+    c["dw_ff2_split_out_1280"] = make_tapgemm(dt, 900, 1280, 5120, out_dtype=dt, residual=True, split_out=True, dualw=True)
     return c
 
 

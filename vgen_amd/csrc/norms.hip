@@ -273,13 +273,33 @@ __global__ __launch_bounds__(256) void gn_finalize_cs_kernel(const float* __rest
   }
 }
 
+// raw copy of the un-normalised input (the ResBlock's 1x1 skip-conv operand): plain 16-bit, or — raw_lo > 0 — as a
+// two-term row [hi | lo] with lo = round16(x - hi) at column offset raw_lo (row stride raw_ld = 2 C)
+template <typename T>
+__device__ __forceinline__ void store_raw4(uint16_t* raw, int64_t off, int raw_lo, const f32x4& v) {
+  const u32x2 h = pack4<T>(v.x, v.y, v.z, v.w);
+  *(u32x2*)(raw + off) = h;
+  if (raw_lo > 0) {
+    *(u32x2*)(raw + off + raw_lo) =
+        pack4<T>(v.x - T::to_f32((uint16_t)(h.x & 0xffffu)), v.y - T::to_f32((uint16_t)(h.x >> 16)),
+                 v.z - T::to_f32((uint16_t)(h.y & 0xffffu)), v.w - T::to_f32((uint16_t)(h.y >> 16)));
+  }
+}
+template <typename T>
+__device__ __forceinline__ void store_raw2(uint16_t* raw, int64_t off, int raw_lo, float a, float b) {
+  const uint32_t h = T::pack2(a, b);
+  *(uint32_t*)(raw + off) = h;
+  if (raw_lo > 0) *(uint32_t*)(raw + off + raw_lo) = T::pack2(a - T::to_f32((uint16_t)(h & 0xffffu)), b - T::to_f32((uint16_t)(h >> 16)));
+}
+
 template <typename T>
 __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(
     const float* __restrict__ x1, int C1, const float* __restrict__ x2, int C2, int64_t S,
     int groups, int nsplit, const float* __restrict__ stat, const float* __restrict__ gamma,
     const float* __restrict__ beta, int silu, uint16_t* __restrict__ y,
-    uint16_t* __restrict__ raw) {
+    uint16_t* __restrict__ raw, int raw_lo) {
   const GnGeom g = gn_geom(C1, C2, groups);
+  const int raw_ld = raw_lo > 0 ? 2 * g.C : g.C;
   const int tid = threadIdx.x;
   const int split = blockIdx.x;
   const int64_t nb = blockIdx.y;
@@ -335,7 +355,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(
             for (int e = 0; e < 4; ++e) o[e] = silu_f(o[e]);
           }
           *(u32x2*)(y + row * g.C + c) = pack4<T>(o.x, o.y, o.z, o.w);
-          if (raw) *(u32x2*)(raw + row * g.C + c) = pack4<T>(cur[u].x, cur[u].y, cur[u].z, cur[u].w);
+          if (raw) store_raw4<T>(raw, row * raw_ld + c, raw_lo, cur[u]);
         }
       }
     }
@@ -355,7 +375,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(
           for (int e = 0; e < 4; ++e) o[e] = silu_f(o[e]);
         }
         *(u32x2*)(y + row * g.C + slot * 4) = pack4<T>(o.x, o.y, o.z, o.w);
-        if (raw) *(u32x2*)(raw + row * g.C + slot * 4) = pack4<T>(v.x, v.y, v.z, v.w);
+        if (raw) store_raw4<T>(raw, row * raw_ld + slot * 4, raw_lo, v);
       }
     }
   }
@@ -388,7 +408,7 @@ template <typename T>
 __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(
     const float* __restrict__ x1, int C1, const float* __restrict__ x2, int C2, int64_t S, int groups,
     float eps, const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
-    uint16_t* __restrict__ y, uint16_t* __restrict__ raw) {
+    uint16_t* __restrict__ y, uint16_t* __restrict__ raw, int raw_lo) {
   extern __shared__ __attribute__((aligned(16))) float gnf_stage[];
   __shared__ float red[GNF_THREADS / 64];
   const int C = C1 + C2;
@@ -431,9 +451,10 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(
   if (!active) return;
   const float sc0 = gamma[c] * rstd, sc1 = gamma[c + 1] * rstd;
   const float sh0 = beta[c] - mean * sc0, sh1 = beta[c + 1] - mean * sc1;
+  const int raw_ld = raw_lo > 0 ? 2 * C : C;
   uint16_t* yo = y + (row0 + r0) * C + c;
-  uint16_t* ro = raw ? raw + (row0 + r0) * C + c : nullptr;
-  const int64_t ostep = (int64_t)rpi * C;
+  uint16_t* ro = raw ? raw + (row0 + r0) * raw_ld + c : nullptr;
+  const int64_t ostep = (int64_t)rpi * C, rstep = (int64_t)rpi * raw_ld;
 #pragma unroll 4
   for (int k = 0; k < nit; ++k) {
     const f32x2 v = st[k * sstep];
@@ -443,7 +464,7 @@ __global__ __launch_bounds__(GNF_THREADS) void gn_fused_kernel(
       o1 = silu_f(o1);
     }
     *(uint32_t*)(yo + k * ostep) = T::pack2(o0, o1);
-    if (ro) *(uint32_t*)(ro + k * ostep) = T::pack2(v.x, v.y);
+    if (ro) store_raw2<T>(ro, k * rstep, raw_lo, v.x, v.y);
   }
 }
 
@@ -472,7 +493,7 @@ template <typename T>
 __global__ __launch_bounds__(GNR_THREADS) void gn_regs_kernel(
     const float* __restrict__ x1, int C1, const float* __restrict__ x2, int C2, int64_t S, int groups,
     float eps, const float* __restrict__ gamma, const float* __restrict__ beta, int silu,
-    uint16_t* __restrict__ y, uint16_t* __restrict__ raw) {
+    uint16_t* __restrict__ y, uint16_t* __restrict__ raw, int raw_lo) {
   __shared__ float red[GNR_THREADS / 64];
   const int C = C1 + C2;
   const int cpg = C / groups;
@@ -516,9 +537,10 @@ __global__ __launch_bounds__(GNR_THREADS) void gn_regs_kernel(
   if (!active) return;
   const float sc0 = gamma[c] * rstd, sc1 = gamma[c + 1] * rstd;
   const float sh0 = beta[c] - mean * sc0, sh1 = beta[c + 1] - mean * sc1;
+  const int raw_ld = raw_lo > 0 ? 2 * C : C;
   uint16_t* yo = y + (row0 + r0) * C + c;
-  uint16_t* ro = raw ? raw + (row0 + r0) * C + c : nullptr;
-  const int64_t ostep = (int64_t)rpi * C;
+  uint16_t* ro = raw ? raw + (row0 + r0) * raw_ld + c : nullptr;
+  const int64_t ostep = (int64_t)rpi * C, rstep = (int64_t)rpi * raw_ld;
 #pragma unroll
   for (int k = 0; k < GNR_NIT; ++k) {
     if (k < nit) {
@@ -528,7 +550,7 @@ __global__ __launch_bounds__(GNR_THREADS) void gn_regs_kernel(
         o1 = silu_f(o1);
       }
       *(uint32_t*)(yo + k * ostep) = T::pack2(o0, o1);
-      if (ro) *(uint32_t*)(ro + k * ostep) = T::pack2(v[k].x, v[k].y);
+      if (ro) store_raw2<T>(ro, k * rstep, raw_lo, v[k].x, v[k].y);
     }
   }
 }
@@ -712,9 +734,10 @@ extern "C" size_t vgen_groupnorm_ws_bytes(int64_t nb, int64_t S) {
 static int groupnorm_impl(const float* x1, int32_t C1, const float* cs1, const float* x2, int32_t C2,
                           const float* cs2, int64_t nb, int64_t S, int32_t groups, float eps,
                           const float* gamma, const float* beta, int32_t silu, void* y,
-                          void* raw, int32_t dtype, float* ws, size_t ws_bytes,
+                          void* raw, int32_t raw_split, int32_t dtype, float* ws, size_t ws_bytes,
                           void* stream) {
   const int C = C1 + C2;
+  const int raw_lo = (raw != nullptr && raw_split) ? C : 0;
   VGEN_REQUIRE(dtype == VGEN_BF16 || dtype == VGEN_F16, "groupnorm: dtype");
   VGEN_REQUIRE(groups > 0 && groups <= GN_G && C % groups == 0, "groupnorm: C=%d groups=%d", C,
                groups);
@@ -756,10 +779,10 @@ static int groupnorm_impl(const float* x1, int32_t C1, const float* cs1, const f
       dim3 fgrid((unsigned)groups, (unsigned)nb);
       if (dtype == VGEN_BF16) {
         hipLaunchKernelGGL(gn_fused_kernel<BF16>, fgrid, dim3(GNF_THREADS), lds, s, x1, C1, x2, C2, S, groups, eps,
-                           gamma, beta, silu, (uint16_t*)y, (uint16_t*)raw);
+                           gamma, beta, silu, (uint16_t*)y, (uint16_t*)raw, raw_lo);
       } else {
         hipLaunchKernelGGL(gn_fused_kernel<F16>, fgrid, dim3(GNF_THREADS), lds, s, x1, C1, x2, C2, S, groups, eps,
-                           gamma, beta, silu, (uint16_t*)y, (uint16_t*)raw);
+                           gamma, beta, silu, (uint16_t*)y, (uint16_t*)raw, raw_lo);
       }
       return vgen_check_launch("gn_fused");
     }
@@ -775,10 +798,10 @@ static int groupnorm_impl(const float* x1, int32_t C1, const float* cs1, const f
       dim3 fgrid((unsigned)groups, (unsigned)nb);
       if (dtype == VGEN_BF16) {
         hipLaunchKernelGGL(gn_regs_kernel<BF16>, fgrid, dim3(GNR_THREADS), 0, s, x1, C1, x2, C2, S, groups, eps, gamma, beta,
-                           silu, (uint16_t*)y, (uint16_t*)raw);
+                           silu, (uint16_t*)y, (uint16_t*)raw, raw_lo);
       } else {
         hipLaunchKernelGGL(gn_regs_kernel<F16>, fgrid, dim3(GNR_THREADS), 0, s, x1, C1, x2, C2, S, groups, eps, gamma, beta,
-                           silu, (uint16_t*)y, (uint16_t*)raw);
+                           silu, (uint16_t*)y, (uint16_t*)raw, raw_lo);
       }
       return vgen_check_launch("gn_regs");
     }
@@ -809,10 +832,10 @@ static int groupnorm_impl(const float* x1, int32_t C1, const float* cs1, const f
   }
   if (dtype == VGEN_BF16) {
     hipLaunchKernelGGL(gn_apply_kernel<BF16>, grid, dim3(GN_THREADS), 0, s, x1, C1, x2, C2, S,
-                       groups, ns, stat, gamma, beta, silu, (uint16_t*)y, (uint16_t*)raw);
+                       groups, ns, stat, gamma, beta, silu, (uint16_t*)y, (uint16_t*)raw, raw_lo);
   } else {
     hipLaunchKernelGGL(gn_apply_kernel<F16>, grid, dim3(GN_THREADS), 0, s, x1, C1, x2, C2, S,
-                       groups, ns, stat, gamma, beta, silu, (uint16_t*)y, (uint16_t*)raw);
+                       groups, ns, stat, gamma, beta, silu, (uint16_t*)y, (uint16_t*)raw, raw_lo);
   }
   return vgen_check_launch("gn_apply");
 }
@@ -820,20 +843,20 @@ static int groupnorm_impl(const float* x1, int32_t C1, const float* cs1, const f
 extern "C" int vgen_groupnorm(const float* x1, int32_t C1, const float* x2, int32_t C2,
                               int64_t nb, int64_t S, int32_t groups, float eps,
                               const float* gamma, const float* beta, int32_t silu, void* y,
-                              void* raw, int32_t dtype, float* ws, size_t ws_bytes,
+                              void* raw, int32_t raw_split, int32_t dtype, float* ws, size_t ws_bytes,
                               void* stream) {
-  return groupnorm_impl(x1, C1, nullptr, x2, C2, nullptr, nb, S, groups, eps, gamma, beta, silu, y, raw,
+  return groupnorm_impl(x1, C1, nullptr, x2, C2, nullptr, nb, S, groups, eps, gamma, beta, silu, y, raw, raw_split,
                         dtype, ws, ws_bytes, stream);
 }
 
 extern "C" int vgen_groupnorm_cs(const float* x1, int32_t C1, const float* cs1, const float* x2,
                                  int32_t C2, const float* cs2, int64_t nb, int64_t S, int32_t groups,
                                  float eps, const float* gamma, const float* beta, int32_t silu,
-                                 void* y, void* raw, int32_t dtype, float* ws, size_t ws_bytes,
+                                 void* y, void* raw, int32_t raw_split, int32_t dtype, float* ws, size_t ws_bytes,
                                  void* stream) {
   VGEN_REQUIRE(cs1 != nullptr && (C2 == 0 || cs2 != nullptr), "groupnorm_cs: missing column statistics");
   VGEN_REQUIRE(S % 64 == 0, "groupnorm_cs: S=%lld must be a multiple of the 64-row slab", (long long)S);
-  return groupnorm_impl(x1, C1, cs1, x2, C2, cs2, nb, S, groups, eps, gamma, beta, silu, y, raw, dtype,
+  return groupnorm_impl(x1, C1, cs1, x2, C2, cs2, nb, S, groups, eps, gamma, beta, silu, y, raw, raw_split, dtype,
                         ws, ws_bytes, stream);
 }
 

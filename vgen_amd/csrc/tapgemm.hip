@@ -662,16 +662,29 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
           }
           return v;
         };
+        // split_out (two-term activation rows, vgen_tapgemm_args.split_out): column n holds hi = round16(v), column
+        // N + n holds round16(v - hi) — the value a separate vgen_cast_split pass over an fp32 output would have written
+        auto lo_of = [&](const f32x4& v) __attribute__((always_inline)) -> f32x4 {
+          const u32x2 h = pack4<T>(v.x, v.y, v.z, v.w);
+          return f32x4{v.x - T::to_f32((uint16_t)(h.x & 0xffffu)), v.y - T::to_f32((uint16_t)(h.x >> 16)),
+                       v.z - T::to_f32((uint16_t)(h.y & 0xffffu)), v.w - T::to_f32((uint16_t)(h.y >> 16))};
+        };
 #pragma unroll
         for (int ni = 0; ni + 1 < NF; ni += 2) {
           const int c0 = n0 + wn * WTN + ni * 16;
-          store_pair16(c0, c0 + 32 <= p.N, final_val(ni), final_val(ni + 1), m);
+          const f32x4 va = final_val(ni), vb = final_val(ni + 1);
+          store_pair16(c0, c0 + 32 <= p.N, va, vb, m);
+          if (p.split_out) store_pair16(p.N + c0, c0 + 32 <= p.N, lo_of(va), lo_of(vb), m);
         }
         if constexpr (NF % 2 == 1) {
           const int n = n0 + wn * WTN + (NF - 1) * 16 + lq * 4;
           if (n < p.N) {
             const f32x4 v = final_val(NF - 1);
             *(u32x2*)(oh + m * p.ldo + n) = pack4<T>(v.x, v.y, v.z, v.w);
+            if (p.split_out) {
+              const f32x4 l = lo_of(v);
+              *(u32x2*)(oh + m * p.ldo + p.N + n) = pack4<T>(l.x, l.y, l.z, l.w);
+            }
           }
         }
       } else if constexpr (NF % 4 == 0) {
@@ -901,7 +914,7 @@ Plan make_plan(const vgen_tapgemm_args& a) {
 #else
   constexpr int force_shape = -1;
 #endif
-  const int smax = (vec && a.colstats == nullptr) ? (KT / 4 < 32 ? KT / 4 : 32) : 1;
+  const int smax = (vec && a.colstats == nullptr && !a.split_out) ? (KT / 4 < 32 ? KT / 4 : 32) : 1;
   // HBM time of the epilogue traffic (output + fp32 residual), not hidden behind MFMAs when every CU
   // runs one block in the same phase ("pp"); about half hidden with two independent blocks per CU
   const double epi_us = (double)a.M * n_out * ((a.out_dtype == VGEN_F32 ? 4 : 2) + (a.residual ? 4 : 0)) / 4.5e6;
@@ -1156,6 +1169,12 @@ extern "C" int vgen_tapgemm(const vgen_tapgemm_args* args, void* stream) {
                      (a.residual == nullptr || a.ldr % 4 == 0) && (a.rowbias == nullptr || a.rowbias_ld % 4 == 0) &&
                      vgen_aligned16(a.colstats),
                  "tapgemm: colstats needs fp32 output, no GEGLU, N/ldo/ldr/rowbias_ld %% 4 == 0");
+  }
+  if (a.split_out) {
+    VGEN_REQUIRE(a.split_out == 1 && a.out_dtype != VGEN_F32 && a.epilogue == VGEN_EPI_NONE && a.colstats == nullptr &&
+                     a.N % 32 == 0 && a.ldo % 8 == 0 && a.ldo >= 2 * (int64_t)a.N && (a.residual == nullptr || a.ldr % 4 == 0) &&
+                     (a.rowbias == nullptr || a.rowbias_ld % 4 == 0),
+                 "tapgemm: split_out needs a 16-bit output [M, >= 2 N], no GEGLU / colstats, N %% 32 == 0, ldo %% 8 == 0");
   }
   hipStream_t s = (hipStream_t)stream;
   return a.dtype == VGEN_BF16 ? dispatch<BF16>(a, s) : dispatch<F16>(a, s);

@@ -38,7 +38,7 @@ class TapGemmArgs(C.Structure):
         ("out", C.c_void_p), ("ldo", C.c_int64), ("out_dtype", C.c_int32),
         ("epilogue", C.c_int32),
         ("ws", C.c_void_p), ("ws_bytes", C.c_size_t), ("crop_t", C.c_int32),
-        ("colstats", C.c_void_p), ("dualw", C.c_int32),
+        ("colstats", C.c_void_p), ("dualw", C.c_int32), ("split_out", C.c_int32),
     ]
 
 
@@ -62,9 +62,9 @@ SYMBOLS = {
     "vgen_last_error": (C.c_char_p, []),
     "vgen_groupnorm_ws_bytes": (_sz, [_i64, _i64]),
     "vgen_groupnorm": (C.c_int, [_vp, _i32, _vp, _i32, _i64, _i64, _i32, _f32, _vp, _vp, _i32,
-                                 _vp, _vp, _i32, _vp, _sz, _vp]),
+                                 _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
     "vgen_groupnorm_cs": (C.c_int, [_vp, _i32, _vp, _vp, _i32, _vp, _i64, _i64, _i32, _f32, _vp, _vp, _i32,
-                                    _vp, _vp, _i32, _vp, _sz, _vp]),
+                                    _vp, _vp, _i32, _i32, _vp, _sz, _vp]),
     "vgen_layernorm": (C.c_int, [_vp, _i64, _i32, _f32, _vp, _vp, _vp, _i32, _vp]),
     "vgen_tapgemm_ws_bytes": (_sz, [C.POINTER(TapGemmArgs)]),
     "vgen_tapgemm": (C.c_int, [C.POINTER(TapGemmArgs), _vp]),

@@ -79,6 +79,7 @@ class TapGemm:
     out: Optional[torch.Tensor] = None        # optional preallocated 2-D view [M, >=N_out]
     colstats: bool = False                    # also emit per-64-row-slab column (sum, sumsq) of the fp32 output;
                                               # attached to the returned tensor as `.vgen_cs` for groupnorm()
+    split_out: bool = False                   # 16-bit output as two-term rows [hi | lo], [M, 2 N] (vgen_tapgemm_args.split_out)
 
 
 @dataclass
@@ -175,28 +176,30 @@ class HipBackend:
 
     # -- norms -----------------------------------------------------------------------------
     def groupnorm(self, x1, x2, nb, S, groups, eps, gamma, beta, silu, want_raw, dt):
+        """want_raw: False | True (plain 16-bit copy [rows, C]) | "split" (two-term copy [rows, 2 C] = [hi | lo])."""
         C1 = x1.shape[1]
         C2 = 0 if x2 is None else x2.shape[1]
         rows = nb * S
         assert x1.dtype == torch.float32 and x1.is_contiguous() and x1.shape[0] == rows
         assert x2 is None or (x2.dtype == torch.float32 and x2.is_contiguous() and x2.shape[0] == rows)
         y = torch.empty((rows, C1 + C2), dtype=dt, device=x1.device)
-        raw = torch.empty_like(y) if want_raw else None
+        rsplit = want_raw == "split"
+        raw = (torch.empty((rows, 2 * (C1 + C2)), dtype=dt, device=x1.device) if rsplit else torch.empty_like(y)) if want_raw else None
         nbytes = self.lib.vgen_groupnorm_ws_bytes(nb, S)
         ws = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=x1.device)
         # column statistics left behind by the producing tap-GEMMs (TapGemm.colstats)
         cs1 = colstats_of(x1, rows)
         cs2 = colstats_of(x2, rows) if x2 is not None else None
         use_cs = S % CS_ROWS == 0 and cs1 is not None and (x2 is None or cs2 is not None)
-        nbytes_moved = rows * (C1 + C2) * ((4 if use_cs else 8) + 2 + (2 if want_raw else 0))
+        nbytes_moved = rows * (C1 + C2) * ((4 if use_cs else 8) + 2 + ((4 if rsplit else 2) if want_raw else 0))
         with self._Prof("groupnorm", nbytes_moved, (nb, S, C1 + C2, int(want_raw))):
             if use_cs:
                 rc = self.lib.vgen_groupnorm_cs(_ptr(x1), C1, _ptr(cs1), _ptr(x2), C2, _ptr(cs2), nb, S, groups,
                                                 float(eps), _ptr(gamma), _ptr(beta), int(bool(silu)), _ptr(y),
-                                                _ptr(raw), _ENUM[dt], _ptr(ws), nbytes, self._stream(x1))
+                                                _ptr(raw), int(rsplit), _ENUM[dt], _ptr(ws), nbytes, self._stream(x1))
             else:
                 rc = self.lib.vgen_groupnorm(_ptr(x1), C1, _ptr(x2), C2, nb, S, groups, float(eps),
-                                             _ptr(gamma), _ptr(beta), int(bool(silu)), _ptr(y), _ptr(raw),
+                                             _ptr(gamma), _ptr(beta), int(bool(silu)), _ptr(y), _ptr(raw), int(rsplit),
                                              _ENUM[dt], _ptr(ws), nbytes, self._stream(x1))
         _lib.check(rc, "vgen_groupnorm")
         return y, raw
@@ -218,10 +221,11 @@ class HipBackend:
         K = g.taps * g.C1 + g.C2
         n_out = g.N // 2 if g.epilogue == _lib.EPI_GEGLU else g.N
         out = g.out
+        w_out = 2 * n_out if g.split_out else n_out
         if out is None:
-            out = torch.empty((g.M, n_out), dtype=g.out_dtype, device=A.device)
+            out = torch.empty((g.M, w_out), dtype=g.out_dtype, device=A.device)
         _mat(out, "out")
-        assert out.dtype == g.out_dtype and out.shape[0] == g.M and out.shape[1] >= n_out
+        assert out.dtype == g.out_dtype and out.shape[0] == g.M and out.shape[1] >= w_out
         a = _lib.TapGemmArgs()
         a.M, a.N, a.dtype = g.M, g.N, _ENUM[A.dtype]
         a.A, a.lda, a.C1, a.taps, a.mode = A.data_ptr(), A.stride(0), g.C1, g.taps, g.mode
@@ -250,6 +254,7 @@ class HipBackend:
             assert r.dtype == torch.float32 and r.shape[0] == g.M
             a.residual, a.ldr = r.data_ptr(), r.stride(0)
         a.out, a.ldo, a.out_dtype, a.epilogue = out.data_ptr(), out.stride(0), _ENUM[g.out_dtype], g.epilogue
+        a.split_out = int(bool(g.split_out))
         cs = None
         if g.colstats and _COLSTATS_ON:
             cs = torch.empty(((g.M + CS_ROWS - 1) // CS_ROWS, 2, g.N), dtype=torch.float32, device=A.device)

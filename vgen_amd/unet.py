@@ -559,15 +559,11 @@ class UNetSD_T2VBase(nn.Module):
         S = H * W
         M = B * F * S
         has_skip = isinstance(rb.skip_connection, nn.Conv2d)
-        a1, raw = be.groupnorm(x1, x2, B * F, S, 32, 1e-5, *P["gn1"], True, has_skip and not self._asplit, dt)
-        c2 = rb.cin
-        if has_skip and self._asplit:
-            # the skip conv's operand as a two-term pair [hi(x1) hi(x2) | lo(x1) lo(x2)] (x = the virtual concat)
-            raw = torch.empty((M, 2 * rb.cin), dtype=dt, device=x1.device)
-            be.cast_split(x1, dt, out=raw, col=0, lo_off=rb.cin)
-            if x2 is not None:
-                be.cast_split(x2, dt, out=raw, col=x1.shape[1], lo_off=rb.cin)
-            c2 = 2 * rb.cin
+        # the skip conv's operand: a plain 16-bit copy of x, or — two-term activations — [hi(x) | lo(x)] rows written by
+        # the same GroupNorm pass (x = the virtual concat [x1 | x2])
+        a1, raw = be.groupnorm(x1, x2, B * F, S, 32, 1e-5, *P["gn1"], True,
+                               ("split" if self._asplit else True) if has_skip else False, dt)
+        c2 = 2 * rb.cin if self._asplit else rb.cin
         rowbias = emb_all[:, rb._emb_off: rb._emb_off + rb.cout]
         # colstats=True: the conv epilogue leaves per-slab column sums behind, so the GroupNorm that
         # consumes this tensor skips its statistics pass (every GN input of the UNet is a tap-GEMM output)
@@ -605,11 +601,9 @@ class UNetSD_T2VBase(nn.Module):
         return self._ff_out(g, P["ff2"], M, x)
 
     def _ff_out(self, g, ff2, M, tok):
-        """tok + FF-out, as the A operand of proj_out: emitted 16-bit straight from the GEMM (sum formed in fp32), or — with
-        two-term activations — fp32 and split into [hi | lo] columns (proj_out's weight is packed twice)."""
-        if not self._asplit:
-            return self._linear(g, ff2, M, residual=tok, out_dtype=self.compute_dtype)
-        return ops.backend().cast_split(self._linear(g, ff2, M, residual=tok), self.compute_dtype)
+        """tok + FF-out, as the A operand of proj_out: emitted 16-bit straight from the GEMM's epilogue (sum formed in fp32)
+        — with two-term activations as [hi | lo] columns (vgen_tapgemm_args.split_out; proj_out's weight is packed twice)."""
+        return self._linear(g, ff2, M, residual=tok, out_dtype=self.compute_dtype, split_out=self._asplit)
 
     def _spatial_tx(self, st: _SpatialTransformerP, x, kv_all, B, F, H, W, Lctx, kv_per_frame=False, share=1,
                     replicate=None):
