@@ -192,7 +192,7 @@ class HipBackend:
         cs2 = colstats_of(x2, rows) if x2 is not None else None
         use_cs = S % CS_ROWS == 0 and cs1 is not None and (x2 is None or cs2 is not None)
         nbytes_moved = rows * (C1 + C2) * ((4 if use_cs else 8) + 2 + ((4 if rsplit else 2) if want_raw else 0))
-        with self._Prof("groupnorm", nbytes_moved, (nb, S, C1 + C2, int(want_raw))):
+        with self._Prof("groupnorm", nbytes_moved, (nb, S, C1 + C2, int(bool(want_raw)) + int(rsplit))):
             if use_cs:
                 rc = self.lib.vgen_groupnorm_cs(_ptr(x1), C1, _ptr(cs1), _ptr(x2), C2, _ptr(cs2), nb, S, groups,
                                                 float(eps), _ptr(gamma), _ptr(beta), int(bool(silu)), _ptr(y),
