@@ -9,9 +9,15 @@ is still called as `model(xt, t=t, **kwargs)` (any callable).
 
 Underneath: classifier-free guidance, guide_rescale (two per-sample std reductions), the
 x0 / eps algebra and the exponential-integrator update run as fused HIP kernels (vgen_cfg_stats,
-vgen_gauss_x0, vgen_lincomb4); the per-step scalars (sigma ratios, expm1 terms) are computed on the
+vgen_gauss_x0, vgen_dpmpp2m_sde_step — one launch per solver update —, vgen_lincomb4); the per-step scalars (sigma ratios, expm1 terms) are computed on the
 host in fp32 exactly as the reference's 0-dim tensor arithmetic; cond/uncond evaluate as one batch
 when the model exposes `forward_units`.
+
+Transcription note: the HOST-side scalar algebra of this file — the step-list preamble of `sample()` (discretisation,
+sigma interpolation `_sigma_to_t / _t_to_sigma`, the penultimate-sigma drop) and the per-step solver coefficients — follows
+the reference's expressions statement by statement (diffusion_gauss.py:249-373, :436-464, :113-139): these are 0-dim fp32
+tensor computations whose rounding order decides the timestep the UNet is asked for, so they are restated, not
+redesigned.  Everything that touches a latent-sized tensor is this repo's own kernels.
 
 Brownian noise: the reference draws the SDE noise from `torchsde.BrownianTree` (torchsde==0.2.6,
 third-party, not vendored -> parity of the stochastic term is unpinned).  torchsde is
