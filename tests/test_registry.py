@@ -56,6 +56,15 @@ def test_extra_kwargs_and_unknown_cfg_keys_are_accepted():
                                      upper_len=128, default_fps=8, misc_dropout=0.4, use_checkpoint=True),
                                 zero_y=None)
     assert m.out_dim == 4
+    # a yaml without a `precision` key resolves to the mode that meets the north-star's 1e-3; the keyword
+    # travels through the registry like any other constructor argument
+    assert m.precision == "mixed" and m._asplit and m.MIXED_LEVELS["enc"] == (0,) and m.MIXED_LEVELS["dec"] == (0,)
+    with torch.device("meta"):
+        mf = regs["MODEL"].build(dict(type="UNetSD_T2VBase", in_dim=4, dim=64, y_dim=1024, context_dim=1024, out_dim=4,
+                                      dim_mult=[1, 2], num_heads=2, head_dim=64, num_res_blocks=1, precision="fast"))
+        mh = regs["MODEL"].build(dict(type="UNetSD_SR600", in_dim=4, dim=64, y_dim=1024, context_dim=1024, out_dim=4,
+                                      dim_mult=[1, 2], num_heads=2, head_dim=64, num_res_blocks=1, precision="high"))
+    assert mf.precision == "fast" and not mf._asplit and mh.precision == "high"
 
 
 @pytest.mark.reference
