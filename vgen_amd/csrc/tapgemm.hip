@@ -113,7 +113,7 @@ __device__ __forceinline__ int swz_key(int row) {
 // still sitting in registers.  r02 ran this product as a K-doubled launch ([A | A] x [W_hi | W_lo], every A tile
 // gathered, DMA'd and ds_read twice) or, for tap gathers, as two launches through an fp32 temporary.
 template <typename T, int BM, int BN, int BK, int WM, int WN, int STAGES, bool PP, bool DW>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && BK == 32) ? 2 : 1) void tapgemm_kernel(
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_kernel(
     const vgen_tapgemm_args p, const int splitk, float* __restrict__ ws, const int ablate_arg) {
   static_assert(!PP || (WM * WN == 8 && STAGES == 3), "ping-pong needs 8 waves and a 3-stage ring");
   static_assert(!DW || (PP && BK == 64), "dual-W K-steps are built on the ping-pong schedule, 64-element K-tiles");
@@ -342,11 +342,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && BK == 32) ? 2 : 1) vo
 
   // A fragments are read in MH passes of MFH row fragments (the 128-row wave tile of the dual shape
   // would otherwise hold 32 + 16 operand registers on top of 128 accumulators and spill)
-  // W4 (experiment, -DVGEN_W4): ONE wave per SIMD — 4 waves, 128-row wave tiles, BK = 64, up to 512 registers per lane: both
-  // fragment sets of a K-tile pair live in registers and the reads / DMA issues of the next tiles are interleaved into this
-  // wave's own MFMA stream (no partner wave to hide behind, 28 % fewer LDS bytes per MFMA than the 64 x 80 wave tile)
-  constexpr bool W4 = !PP && BK == 64 && WM * WN == 4;
-  constexpr int MH = (MF > 4 && !W4) ? MF / 4 : 1;
+  constexpr int MH = MF > 4 ? MF / 4 : 1;
   constexpr int MFH = MF / MH;
   u32x4 wf[KS][NF], xf[KS][MFH];
   auto read_w = [&](int stage) __attribute__((always_inline)) {
@@ -563,75 +559,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4 && BK == 32) ? 2 : 1) vo
     for (int it = 0; it < nk_main; ++it) pp_step(std::true_type{}, true);
     for (int it = nk_main; it < nk; ++it) pp_step(std::false_type{}, false);
     if (!follower) __builtin_amdgcn_s_barrier();
-  } else if constexpr (W4) {
-    // iteration `it` multiplies tile `it` out of one register set; its first half (k-step 0) carries the DMA pieces of tile
-    // it+2, then the counted wait + barrier publish tile it+1, and its second half (k-step 1) carries the fragment reads
-    // of tile it+1 into the other register set.  One barrier per K-tile.
-    // Register plan: ONE buffer per k-step (wf/xf[0] = k-step 0, [1] = k-step 1 of the current tile).  The first half of an
-    // iteration multiplies k-step 0 while the reads of THIS tile's k-step 1 land in buffer 1; the second half multiplies
-    // k-step 1 while the reads of the NEXT tile's k-step 0 land in buffer 0 — no second fragment set.
-    auto w4_reads = [&](int stage, int ks, int j, int nmh) __attribute__((always_inline)) {
-      // the (NF + MF) fragment reads of one k-step, spread over the nmh MFMAs of a half iteration: slice j
-      const unsigned char* bw = smem + stage * STAGE_BYTES + BM * ROW_BYTES + wn * WTN * ROW_BYTES + rd_row;
-      const unsigned char* bx = smem + stage * STAGE_BYTES + (wm * WTM) * ROW_BYTES + rd_row;
-      const int co = ((ks * 4 + lq) ^ sw) << 4;
-      const int r0 = (j * (NF + MF)) / nmh, r1 = ((j + 1) * (NF + MF)) / nmh;
-#pragma unroll
-      for (int q = r0; q < r1; ++q) {
-        if (q < NF) wf[ks][q] = *(const u32x4*)(bw + q * 16 * ROW_BYTES + co);
-        else xf[ks][q - NF] = *(const u32x4*)(bx + (q - NF) * 16 * ROW_BYTES + co);
-      }
-    };
-    auto w4_iter = [&](auto pf_tag, auto more_tag) __attribute__((always_inline)) {
-      constexpr bool pf = decltype(pf_tag)::value;       // tile it+2 exists: issue its DMA
-      constexpr bool more = decltype(more_tag)::value;   // tile it+1 exists: publish it and read its k-step 0
-      static_assert(KS == 2, "W4 is written for two k-steps per K-tile");
-      constexpr int NMH = NF * MF;                       // MFMAs per k-step
-#pragma unroll
-      for (int j = 0; j < NMH; ++j) {
-        const int ni = j / MF, mi = j % MF;
-        w4_reads(st_c, 1, j, NMH);                       // k-step 1 of THIS tile
-        if constexpr (pf) {
-          const int p0 = (j * NP) / NMH, p1 = ((j + 1) * NP) / NMH;      // the NP DMA pieces of tile it+2
-#pragma unroll
-          for (int q = p0; q < p1; ++q) {
-            if (q < LPT) glds16(pc[q], piece_dst(st_l, q));
-            else if (RBT > 0 && w_tail) glds16(pc[NP - 1], piece_dst(st_l, NP - 1));
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        acc[ni][mi] = T::mfma32(wf[0][ni], xf[0][mi], acc[ni][mi]);
-      }
-      if constexpr (pf) advance();
-      if constexpr (more) {
-        if constexpr (pf) wait_next();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-      }
-      const int st_n = st_c == STAGES - 1 ? 0 : st_c + 1;
-#pragma unroll
-      for (int j = 0; j < NMH; ++j) {
-        const int ni = j / MF, mi = j % MF;
-        if constexpr (more) w4_reads(st_n, 0, j, NMH);   // k-step 0 of the NEXT tile (buffer 0 is free again)
-        __builtin_amdgcn_sched_barrier(0);
-        acc[ni][mi] = T::mfma32(wf[1][ni], xf[1][mi], acc[ni][mi]);
-      }
-      rotate();
-    };
-    using TT = std::true_type;
-    using FF = std::false_type;
-    if (nk > 0) {
-      if (nk > 1) wait_next();
-      else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      asm volatile("" ::: "memory");
-#pragma unroll
-      for (int j = 0; j < NF + MF; ++j) w4_reads(st_c, 0, j, NF + MF);   // k-step 0 of tile 0
-      for (int it = 0; it < nk_main; ++it) w4_iter(TT{}, TT{});
-      if (nk >= 2) w4_iter(FF{}, TT{});
-      w4_iter(FF{}, FF{});
-    }
   } else {
     // Iteration `it`: wait until tile `it` has landed (the DMA of tile it+1 may stay in flight),
     // barrier (publishes tile `it` of every wave AND proves every wave finished reading the stage
@@ -939,7 +866,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vgen_tapgemm_a
 // small cost model (microseconds; constants fitted to profiles/r01_*_tapgemm_shapes.json):
 //   cost = rounds(tiles * s / slots) * (ceil(KT / s) * t_ktile + t_tile) + [s > 1] * reduce(s)
 // with KT in 64-element K-steps, slots = 256 ("pp", one block per CU) or 512 ("dual").
-enum Shape { SHAPE_PP = 0, SHAPE_DUAL = 1, SHAPE_PP128 = 2, SHAPE_W4 = 3 };
+enum Shape { SHAPE_PP = 0, SHAPE_DUAL = 1, SHAPE_PP128 = 2 };
 
 struct Plan {
   int shape;
@@ -1062,9 +989,6 @@ Plan make_plan(const vgen_tapgemm_args& a) {
       }
     }
   }
-#ifdef VGEN_W4
-  if (best.shape == SHAPE_PP && !a.dualw && (best.bn == 128 || best.bn == 160)) best.shape = SHAPE_W4;
-#endif
   return best;
 }
 
@@ -1140,14 +1064,6 @@ int dispatch(const vgen_tapgemm_args& a, hipStream_t s) {
       default: return launch<T, 128, 64, 64, 4, 2, 3, true>(a, pl.splitk, s);
     }
   }
-#ifdef VGEN_W4
-  if (pl.shape == SHAPE_W4) {
-    switch (pl.bn) {
-      case 128: return launch<T, 256, 128, 64, 2, 2, 3, false>(a, pl.splitk, s);
-      default: return launch<T, 256, 160, 64, 2, 2, 3, false>(a, pl.splitk, s);
-    }
-  }
-#endif
   switch (pl.bn) {
     case 128: return launch<T, 256, 128, 32, 2, 2, 3, false>(a, pl.splitk, s);
     case 160: return launch<T, 256, 160, 32, 2, 2, 3, false>(a, pl.splitk, s);
