@@ -218,6 +218,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   // (v3a recomputed rows, bounds and 64-bit products every K-tile: ~700 ALU instructions per wave
   // per K-tile against 32 MFMAs — the loop was issue-bound, not memory- or MFMA-bound.)
   constexpr int NP = LPT + (RBT > 0 ? 1 : 0);
+#ifdef VGEN_MPH
+  // experiment: DMA pieces deferred from the read phase into the matrix phase
+  constexpr int MPH = !PP ? 0 : (VGEN_MPH < NP - 2 ? VGEN_MPH : NP - 2);
+#else
+  constexpr int MPH = 0;
+#endif
   const char* pc[NP];
   const char* const zline = (const char*)g_zeros;
   const int src_cb = (ld_c ^ swz_key<CPR>(ld_r)) * 16;   // byte offset of this lane's source chunk
@@ -425,7 +431,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
     const unsigned char* bw = smem + stage * STAGE_BYTES + BM * ROW_BYTES + wn * WTN * ROW_BYTES + rd_row;
     const unsigned char* bx = smem + stage * STAGE_BYTES + (wm * WTM) * ROW_BYTES + rd_row;
     constexpr int P0 = odd ? RA : 0;                   // first DMA piece this phase issues
-    constexpr int NPI = NP - P0;
+    constexpr int PE = NP - ((prefetch && !odd) ? MPH : 0);   // one past the last piece this phase issues
+    constexpr int NPI = PE - P0;
     constexpr int NRF = odd ? NF : NF + MF;            // fragment reads per k-step
     constexpr int NR = KS * NRF;                       // fragment reads per wave and K-tile
     constexpr int EVERY = (NR + NPI) / (NPI + 1) > 0 ? (NR + NPI) / (NPI + 1) : 1;   // reads between two DMA issues (3)
@@ -436,7 +443,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
       const int co = ((ks * 4 + lq) ^ sw) << 4;
       if (q < NF) wf[ks][q] = *(const u32x4*)(bw + q * 16 * ROW_BYTES + co);
       else xf[ks][q - NF] = *(const u32x4*)(bx + (q - NF) * 16 * ROW_BYTES + co);
-      if (prefetch && (r % EVERY) == EVERY - 1 && piece < NP) {
+      if (prefetch && (r % EVERY) == EVERY - 1 && piece < PE) {
         __builtin_amdgcn_sched_barrier(0);
         if (piece < LPT) glds16(pc[piece], piece_dst(stage_pf, piece));
         else if (RBT > 0 && w_tail) glds16(pc[NP - 1], piece_dst(stage_pf, NP - 1));
@@ -446,20 +453,31 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
     }
     if (prefetch) {
 #pragma unroll
-      for (int j = 0; j < NP; ++j)
+      for (int j = 0; j < PE; ++j)
         if (j >= piece) {
           if (j < LPT) glds16(pc[j], piece_dst(stage_pf, j));
           else if (RBT > 0 && w_tail) glds16(pc[NP - 1], piece_dst(stage_pf, NP - 1));
         }
     }
   };
-  auto mfma_phase = [&]() __attribute__((always_inline)) {
+  // `late_tag`: the last MPH pieces of the tile the preceding read phase prefetched are issued HERE, spread over the
+  // MFMA stream (experiment VGEN_MPH: the read phase is the long half of a K-step and most of it is DMA issue).
+  auto mfma_phase = [&](auto late_tag, int stage_pf) __attribute__((always_inline)) {
+    constexpr bool late = decltype(late_tag)::value && MPH > 0;
+    constexpr int NMF = KS * NF * MF;
+    constexpr int GAP = NMF / (MPH + 1);
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-      for (int ni = 0; ni < NF; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < MF; ++mi) acc[ni][mi] = T::mfma32(wf[ks][ni], xf[ks][mi], acc[ni][mi]);
+    for (int i = 0; i < NMF; ++i) {
+      const int ks = i / (NF * MF), r = i % (NF * MF), ni = r / MF, mi = r % MF;
+      if (late && i % GAP == 0 && i > 0 && i / GAP <= MPH) {
+        const int piece = NP - MPH + i / GAP - 1;
+        __builtin_amdgcn_sched_barrier(0);
+        if (piece < LPT) glds16(pc[piece], piece_dst(stage_pf, piece));
+        else if (RBT > 0 && w_tail) glds16(pc[NP - 1], piece_dst(stage_pf, NP - 1));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      acc[ni][mi] = T::mfma32(wf[ks][ni], xf[ks][mi], acc[ni][mi]);
+    }
   };
 
   // ---- main loop: STAGES-deep DMA ring, counted vmcnt -------------------------------------------
@@ -487,6 +505,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
     if (w_tail) wait_vmcnt<LPT + 1>();
     else wait_vmcnt<LPT>();
   };
+  auto wait_next_r = [&]() __attribute__((always_inline)) {   // ... at the end of a read phase that issued NP - MPH of them
+    if constexpr (MPH > 0) wait_vmcnt<NP - MPH>();          // (the tail piece, if any, is among the deferred ones)
+    else wait_next();
+  };
   auto wait_next_w = [&]() __attribute__((always_inline)) {   // ... when the newest tile is a dual-W odd one (W pieces only)
     if (w_tail) wait_vmcnt<LPT - RA + 1>();
     else wait_vmcnt<LPT - RA>();
@@ -506,14 +528,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
         read_phase(st_c, prefetch_tag, st_l, odd_tag);
         if constexpr (pf) {
           if constexpr (odd) wait_next_w();             // tile it+1 (even: full) landed, it+2 (odd: W only) may fly
-          else wait_next();                             // tile it+1 (odd) landed, it+2 (even: full) may fly
+          else wait_next_r();                           // tile it+1 (odd) landed, it+2 (even: full) may fly
         } else {
           wait_vmcnt<0>();
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        mfma_phase();
+        mfma_phase(std::integral_constant<bool, pf && !odd>{}, st_l);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (pf) {
           if constexpr (!odd) advance_a();
@@ -541,12 +563,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
     auto pp_step = [&](auto prefetch_tag, bool more) __attribute__((always_inline)) {
       read_phase(st_c, prefetch_tag, st_l, std::false_type{});
       // tile it+1 (issued one iteration ago) must have landed before the NEXT read phase of anyone
-      if (more) wait_next();
+      if (more) wait_next_r();
       else wait_vmcnt<0>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);
-      mfma_phase();
+      mfma_phase(prefetch_tag, st_l);
       __builtin_amdgcn_sched_barrier(0);
       // the pointer step of this wave's next DMA issue runs here, behind the queued MFMAs: a K-step lasts two READ
       // phases (the matrix phase of one wave group hides under the read phase of the other), so VALU work moved
