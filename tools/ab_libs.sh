@@ -10,6 +10,6 @@ for r in $(seq 1 $ROUNDS); do
     tag=$(basename $lib .so)
     VGEN_HIP_LIB=$PWD/$lib timeout 300 python bench.py $ARGS 2>/dev/null | tail -1 | python -c "
 import sys, json
-d = json.loads(sys.stdin.read()); print(json.dumps({'lib': '$tag', 'round': $r, 'ms_per_step': d['ms_per_step'], 'precision': d['config']['precision'], 'dtype': d['dtype']}))" | tee -a gpurun_out/ab.jsonl
+d = json.loads(sys.stdin.read()); print(json.dumps({'lib': '$tag', 'round': $r, 'ms_per_step': d['ms_per_step'], 'precision': d['config']['precision'], 'dtype': d['dtype'], 'parity_rel_l2': (d.get('parity') or {}).get('unet_rel_l2')}))" | tee -a gpurun_out/ab.jsonl
   done
 done

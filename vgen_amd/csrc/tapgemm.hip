@@ -72,6 +72,27 @@ __device__ __attribute__((aligned(128))) unsigned char g_zeros[ZERO_BYTES];
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
+// -DVGEN_STAMP (probe build only, tools/stamp_probe.py): every wave of the first 64 blocks sums the s_memtime cycles it
+// spends in each segment of a ping-pong K-step into 12 counters and stores them after the K loop (no store inside the
+// loop: gfx950 counts stores in vmcnt).  Segments: 0 read phase issued + fragments landed, 1 counted vmcnt wait,
+// 2 barrier before the matrix phase, 3 matrix phase issued, 4 pointer step + barrier after it; 5-9 the same for the odd
+// step of a dual-W pair; 10 = K-steps, 11 = whole loop.
+#ifdef VGEN_STAMP
+constexpr int STAMP_SLOTS = 12, STAMP_BLOCKS = 64;
+__device__ unsigned long long g_stamp[STAMP_BLOCKS * 8 * STAMP_SLOTS];
+#define VGEN_STAMP_AT(k)                                         \
+  do {                                                           \
+    __builtin_amdgcn_sched_barrier(0);                           \
+    const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           \
+    st_acc[k] += t_ - st_prev;                                   \
+    st_prev = t_;                                                \
+    __builtin_amdgcn_sched_barrier(0);                           \
+  } while (0)
+#else
+#define VGEN_STAMP_AT(k)
+#endif
+
 __device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_base) {
   // 64 lanes x 16 B -> LDS [lds_wave_base + lane*16]; the LDS base must be wave-uniform
   __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
@@ -218,12 +239,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   // (v3a recomputed rows, bounds and 64-bit products every K-tile: ~700 ALU instructions per wave
   // per K-tile against 32 MFMAs — the loop was issue-bound, not memory- or MFMA-bound.)
   constexpr int NP = LPT + (RBT > 0 ? 1 : 0);
-#ifdef VGEN_MPH
-  // experiment: DMA pieces deferred from the read phase into the matrix phase
-  constexpr int MPH = !PP ? 0 : (VGEN_MPH < NP - 2 ? VGEN_MPH : NP - 2);
-#else
-  constexpr int MPH = 0;
-#endif
   const char* pc[NP];
   const char* const zline = (const char*)g_zeros;
   const int src_cb = (ld_c ^ swz_key<CPR>(ld_r)) * 16;   // byte offset of this lane's source chunk
@@ -231,43 +246,56 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   int kt_next = kt_begin;                        // K-tile the pointers currently describe
   int left;                                      // K-tiles until the A pointers must be regathered
 
+  // Branch-free regather (r03).  The first version compiled `ok ? A + row * lda : zline` with 64-bit row / stride
+  // products into a diamond per piece (350 instructions in ~25 basic blocks, exec-mask branches): the s_memtime probe
+  // (tools/stamp_probe.py, profiles/r03l_kstep_stamps_base.json) put the pointer step of a 3x3 conv at ~300 cycles per
+  // K-step averaged over the tap's K-tiles — on the matrix-phase side of the ping-pong, i.e. on its critical path.  Now:
+  // 32-bit source row (validated on the host), one v_mad_u64_u32 per piece, predication instead of branches (~150
+  // instructions): whole step -1.2 / -1.3 % (mixed / single-pass) in a same-box A/B, profiles/r03m_ab_gather.jsonl.
+  const unsigned lda_b = (unsigned)p.lda * 2u, lda2_b = (unsigned)p.lda2 * 2u;     // row strides in bytes (< 2^31)
+  const char* const zl = zline + src_cb;
   auto gather_a = [&](int kt) __attribute__((always_inline)) {   // (re)compute pc[0..RA) for K-tile kt
     if (kt < T1) {
       const int tap = kt / cpt1;
       const int cch = kt - tap * cpt1;
       left = cpt1 - cch;
-      int d0 = 0, d1 = 0;
+      const char* const a_cb = (const char*)A + (cch * BK * 2 + src_cb);
       if (p.mode == VGEN_TAP_CONV3X3) {
-        d0 = tap / 3;
-        d1 = tap - 3 * d0;
-      }
-      const int Hv = (p.Hi << p.ups) - 2 * p.crop_t, Wv = p.Wi << p.ups;
+        const int d0 = tap / 3, d1 = tap - 3 * d0;
+        const unsigned Hv = (unsigned)((p.Hi << p.ups) - 2 * p.crop_t), Wv = (unsigned)(p.Wi << p.ups);
 #pragma unroll
-      for (int i = 0; i < RA; ++i) {
-        int64_t row;
-        bool ok;
-        if (p.mode == VGEN_TAP_CONV3X3) {
-          const int iy = rs[i].a + d0;
-          const int ix = rs[i].b + d1;
-          ok = (iy >= 0) & (iy < Hv) & (ix >= 0) & (ix < Wv);
-          row = (int64_t)rs[i].base + (int64_t)((iy + p.crop_t) >> p.ups) * p.Wi + (ix >> p.ups);
-        } else if (p.mode == VGEN_TAP_TEMPORAL3) {
-          const int f2 = rs[i].a + tap - 1;
-          ok = (f2 >= 0) & (f2 < p.F);
-          row = (int64_t)rs[i].base + (int64_t)(tap - 1) * p.S;
-        } else {
-          ok = rs[i].base >= 0;
-          row = rs[i].base;
+        for (int i = 0; i < RA; ++i) {
+          const int iy = rs[i].a + d0, ix = rs[i].b + d1;
+          const bool ok = ((unsigned)iy < Hv) & ((unsigned)ix < Wv);
+          const unsigned row = (unsigned)rs[i].base + (unsigned)((iy + p.crop_t) >> p.ups) * (unsigned)p.Wi + (unsigned)(ix >> p.ups);
+          const char* const real = a_cb + (uint64_t)row * lda_b;
+          pc[i] = ok ? real : zl;
         }
-        pc[i] = (ok ? (const char*)(A + row * p.lda + cch * BK) : zline) + src_cb;
+      } else if (p.mode == VGEN_TAP_TEMPORAL3) {
+        const int dt_ = tap - 1;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+          const bool ok = (unsigned)(rs[i].a + dt_) < (unsigned)p.F;
+          const unsigned row = (unsigned)(rs[i].base + dt_ * p.S);
+          const char* const real = a_cb + (uint64_t)row * lda_b;
+          pc[i] = ok ? real : zl;
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+          const bool ok = rs[i].base >= 0;
+          const char* const real = a_cb + (uint64_t)(unsigned)rs[i].base * lda_b;
+          pc[i] = ok ? real : zl;
+        }
       }
     } else {
       left = KT - kt + 1;
+      const char* const a_cb = (const char*)A2 + ((kt - T1) * BK * 2 + src_cb);
 #pragma unroll
       for (int i = 0; i < RA; ++i) {
         const bool ok = (mvalid >> i) & 1u;
-        pc[i] = (ok ? (const char*)(A2 + (int64_t)((unsigned)lm0 + ld_r + RPP * i) * p.lda2 + (kt - T1) * BK) : zline) +
-                src_cb;
+        const char* const real = a_cb + (uint64_t)((unsigned)lm0 + ld_r + RPP * i) * lda2_b;
+        pc[i] = ok ? real : zl;
       }
     }
   };
@@ -431,8 +459,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
     const unsigned char* bw = smem + stage * STAGE_BYTES + BM * ROW_BYTES + wn * WTN * ROW_BYTES + rd_row;
     const unsigned char* bx = smem + stage * STAGE_BYTES + (wm * WTM) * ROW_BYTES + rd_row;
     constexpr int P0 = odd ? RA : 0;                   // first DMA piece this phase issues
-    constexpr int PE = NP - ((prefetch && !odd) ? MPH : 0);   // one past the last piece this phase issues
-    constexpr int NPI = PE - P0;
+    constexpr int NPI = NP - P0;
     constexpr int NRF = odd ? NF : NF + MF;            // fragment reads per k-step
     constexpr int NR = KS * NRF;                       // fragment reads per wave and K-tile
     constexpr int EVERY = (NR + NPI) / (NPI + 1) > 0 ? (NR + NPI) / (NPI + 1) : 1;   // reads between two DMA issues (3)
@@ -443,7 +470,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
       const int co = ((ks * 4 + lq) ^ sw) << 4;
       if (q < NF) wf[ks][q] = *(const u32x4*)(bw + q * 16 * ROW_BYTES + co);
       else xf[ks][q - NF] = *(const u32x4*)(bx + (q - NF) * 16 * ROW_BYTES + co);
-      if (prefetch && (r % EVERY) == EVERY - 1 && piece < PE) {
+      if (prefetch && (r % EVERY) == EVERY - 1 && piece < NP) {
         __builtin_amdgcn_sched_barrier(0);
         if (piece < LPT) glds16(pc[piece], piece_dst(stage_pf, piece));
         else if (RBT > 0 && w_tail) glds16(pc[NP - 1], piece_dst(stage_pf, NP - 1));
@@ -453,31 +480,20 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
     }
     if (prefetch) {
 #pragma unroll
-      for (int j = 0; j < PE; ++j)
+      for (int j = 0; j < NP; ++j)
         if (j >= piece) {
           if (j < LPT) glds16(pc[j], piece_dst(stage_pf, j));
           else if (RBT > 0 && w_tail) glds16(pc[NP - 1], piece_dst(stage_pf, NP - 1));
         }
     }
   };
-  // `late_tag`: the last MPH pieces of the tile the preceding read phase prefetched are issued HERE, spread over the
-  // MFMA stream (experiment VGEN_MPH: the read phase is the long half of a K-step and most of it is DMA issue).
-  auto mfma_phase = [&](auto late_tag, int stage_pf) __attribute__((always_inline)) {
-    constexpr bool late = decltype(late_tag)::value && MPH > 0;
-    constexpr int NMF = KS * NF * MF;
-    constexpr int GAP = NMF / (MPH + 1);
+  auto mfma_phase = [&]() __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < NMF; ++i) {
-      const int ks = i / (NF * MF), r = i % (NF * MF), ni = r / MF, mi = r % MF;
-      if (late && i % GAP == 0 && i > 0 && i / GAP <= MPH) {
-        const int piece = NP - MPH + i / GAP - 1;
-        __builtin_amdgcn_sched_barrier(0);
-        if (piece < LPT) glds16(pc[piece], piece_dst(stage_pf, piece));
-        else if (RBT > 0 && w_tail) glds16(pc[NP - 1], piece_dst(stage_pf, NP - 1));
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      acc[ni][mi] = T::mfma32(wf[ks][ni], xf[ks][mi], acc[ni][mi]);
-    }
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int ni = 0; ni < NF; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MF; ++mi) acc[ni][mi] = T::mfma32(wf[ks][ni], xf[ks][mi], acc[ni][mi]);
   };
 
   // ---- main loop: STAGES-deep DMA ring, counted vmcnt -------------------------------------------
@@ -505,14 +521,14 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
     if (w_tail) wait_vmcnt<LPT + 1>();
     else wait_vmcnt<LPT>();
   };
-  auto wait_next_r = [&]() __attribute__((always_inline)) {   // ... at the end of a read phase that issued NP - MPH of them
-    if constexpr (MPH > 0) wait_vmcnt<NP - MPH>();          // (the tail piece, if any, is among the deferred ones)
-    else wait_next();
-  };
   auto wait_next_w = [&]() __attribute__((always_inline)) {   // ... when the newest tile is a dual-W odd one (W pieces only)
     if (w_tail) wait_vmcnt<LPT - RA + 1>();
     else wait_vmcnt<LPT - RA>();
   };
+#ifdef VGEN_STAMP
+  unsigned long long st_acc[STAMP_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long st_prev = 0, st_t0 = 0;
+#endif
   if constexpr (PP && DW) {
     // K-steps come in (even, odd) pairs: nk is even.  Tile t+2 has the parity of tile t, so an even step issues (and
     // leaves in flight) a full tile, an odd step the W pieces only; each waits for the tile of the OTHER parity.
@@ -522,26 +538,36 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
       __builtin_amdgcn_s_barrier();
       if (follower) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+#ifdef VGEN_STAMP
+      st_prev = st_t0 = __builtin_amdgcn_s_memtime();
+#endif
       auto dw_step = [&](auto prefetch_tag, auto odd_tag) __attribute__((always_inline)) {
         constexpr bool pf = decltype(prefetch_tag)::value;
         constexpr bool odd = decltype(odd_tag)::value;
+        constexpr int SB = odd ? 5 : 0;
+        (void)SB;
         read_phase(st_c, prefetch_tag, st_l, odd_tag);
+        VGEN_STAMP_AT(SB + 0);
         if constexpr (pf) {
           if constexpr (odd) wait_next_w();             // tile it+1 (even: full) landed, it+2 (odd: W only) may fly
-          else wait_next_r();                           // tile it+1 (odd) landed, it+2 (even: full) may fly
+          else wait_next();                             // tile it+1 (odd) landed, it+2 (even: full) may fly
         } else {
           wait_vmcnt<0>();
         }
+        VGEN_STAMP_AT(SB + 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        VGEN_STAMP_AT(SB + 2);
         __builtin_amdgcn_sched_barrier(0);
-        mfma_phase(std::integral_constant<bool, pf && !odd>{}, st_l);
+        mfma_phase();
         __builtin_amdgcn_sched_barrier(0);
+        VGEN_STAMP_AT(SB + 3);
         if constexpr (pf) {
           if constexpr (!odd) advance_a();
           advance_w();
         }
         __builtin_amdgcn_s_barrier();
+        VGEN_STAMP_AT(SB + 4);
         asm volatile("" ::: "memory");
         rotate();
       };
@@ -560,21 +586,29 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
     __builtin_amdgcn_s_barrier();                       // tile 0 published
     if (follower) __builtin_amdgcn_s_barrier();         // run one phase behind
     asm volatile("" ::: "memory");
+#ifdef VGEN_STAMP
+    st_prev = st_t0 = __builtin_amdgcn_s_memtime();
+#endif
     auto pp_step = [&](auto prefetch_tag, bool more) __attribute__((always_inline)) {
       read_phase(st_c, prefetch_tag, st_l, std::false_type{});
+      VGEN_STAMP_AT(0);
       // tile it+1 (issued one iteration ago) must have landed before the NEXT read phase of anyone
-      if (more) wait_next_r();
+      if (more) wait_next();
       else wait_vmcnt<0>();
+      VGEN_STAMP_AT(1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      VGEN_STAMP_AT(2);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_phase(prefetch_tag, st_l);
+      mfma_phase();
       __builtin_amdgcn_sched_barrier(0);
+      VGEN_STAMP_AT(3);
       // the pointer step of this wave's next DMA issue runs here, behind the queued MFMAs: a K-step lasts two READ
       // phases (the matrix phase of one wave group hides under the read phase of the other), so VALU work moved
       // out of the read phase shortens the step twice over
       if (decltype(prefetch_tag)::value) advance();
       __builtin_amdgcn_s_barrier();
+      VGEN_STAMP_AT(4);
       asm volatile("" ::: "memory");
       rotate();
     };
@@ -604,6 +638,16 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
     }
   }
 
+#ifdef VGEN_STAMP
+  if constexpr (PP) {
+    st_acc[10] = (unsigned long long)nk;
+    st_acc[11] = st_prev - st_t0;
+    if ((int)blockIdx.x < STAMP_BLOCKS && (threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int k = 0; k < STAMP_SLOTS; ++k) g_stamp[((int)blockIdx.x * 8 + wave) * STAMP_SLOTS + k] = st_acc[k];
+    }
+  }
+#endif
   if (splitk > 1) {   // raw fp32 partial tile -> workspace [split][M][N]; epilogue in the reducer
     float* const wsp = ws + (int64_t)split * p.M * p.N;
 #pragma unroll
@@ -1176,6 +1220,8 @@ extern "C" int vgen_tapgemm(const vgen_tapgemm_args* args, void* stream) {
       return VGEN_E_BADARG;
   }
   VGEN_REQUIRE(a.M + 256 < (1LL << 31), "tapgemm: M overflows int32 row index");
+  VGEN_REQUIRE(a.lda >= 0 && a.lda < (1LL << 30) && a.lda2 >= 0 && a.lda2 < (1LL << 30),
+               "tapgemm: lda / lda2 must be in [0, 2^30)");
   VGEN_REQUIRE(((int64_t)a.taps * a.C1 + a.C2) * (a.dualw ? 4 : 2) <= ZERO_BYTES - 128,
                "tapgemm: K = %lld too long (<= 131008; <= 65504 with dualw)",
                (long long)((int64_t)a.taps * a.C1 + a.C2));
@@ -1201,3 +1247,17 @@ extern "C" int vgen_tapgemm(const vgen_tapgemm_args* args, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   return a.dtype == VGEN_BF16 ? dispatch<BF16>(a, s) : dispatch<F16>(a, s);
 }
+
+#ifdef VGEN_STAMP
+// probe build only (not declared in include/vgen_hip.h): copy the segment counters of the last launch to a device buffer
+namespace {
+__global__ void stamp_copy_kernel(unsigned long long* dst) {
+  const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
+  if (i < STAMP_BLOCKS * 8 * STAMP_SLOTS) dst[i] = g_stamp[i];
+}
+}  // namespace
+extern "C" __attribute__((visibility("default"))) int vgen_debug_stamps(void* dev_dst, void* stream) {
+  stamp_copy_kernel<<<(STAMP_BLOCKS * 8 * STAMP_SLOTS + 255) / 256, 256, 0, (hipStream_t)stream>>>((unsigned long long*)dev_dst);
+  return (int)hipGetLastError();
+}
+#endif
