@@ -98,6 +98,36 @@ __device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_
   __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
+#ifdef VGEN_BUFCHECK
+// self-checking probe build of the BUFDMA experiment: every DMA issue recomputes the address the pointer path would
+// use from first principles and records the first disagreement (tools/probes/tapgemm_ab.cpp prints it)
+__device__ unsigned long long g_dbg[16];
+#endif
+#ifdef VGEN_BUFDMA
+// experiment: the same DMA as `buffer_load_dwordx4 ... offen lds` — 128-bit resource + scalar byte offset in SGPRs, one
+// 32-bit per-lane offset: the per-K-tile pointer step becomes one s_add per operand instead of a 64-bit VALU add per
+// piece, and a row that must read zeros is an out-of-range offset (no zero region, no select)
+constexpr unsigned BUF_OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
+}
+// A wave-uniform value that went through the VALU (an integer division) pinned to an SGPR.  Inline asm on purpose:
+// hipcc folds __builtin_amdgcn_readfirstlane of a value its IR analysis calls uniform, instruction selection then finds
+// the value in a VGPR anyway and wraps every buffer_load that takes it as a scalar operand in a waterfall loop.
+// The hazard recognizer does not look inside inline asm, so both hazards are padded by hand: gfx950 needs a wait state
+// between a VALU write of a VGPR and a v_readfirstlane of it (hipcc puts `s_nop 0` there itself; without it the first
+// self-checking run, tools/probes/tapgemm_ab.cpp, read STALE lane-0 contents: profiles/r03o_bufdma_selfcheck.txt), and
+// five between a VALU write of an SGPR and a VMEM instruction that reads it.
+__device__ __forceinline__ int to_sgpr(int x) {
+  int r;
+  asm volatile("s_nop 1\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(r) : "v"(x));
+  return r;
+}
+__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)lds_wave_base, 16, (int)voff, soff, 0, 0);
+}
+#endif
+
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -224,8 +254,13 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   const int KT = T1 + p.C2 / BK;        // K-tiles of the A side (the W side has WPA per A tile)
   // this block's K-tile range (split-K: blockIdx.y)
   const int split = blockIdx.y;
+#ifdef VGEN_BUFDMA
+  const int kt_begin = to_sgpr((int)(((int64_t)KT * split) / splitk));
+  const int kt_end = to_sgpr((int)(((int64_t)KT * (split + 1)) / splitk));
+#else
   const int kt_begin = (int)(((int64_t)KT * split) / splitk);
   const int kt_end = (int)(((int64_t)KT * (split + 1)) / splitk);
+#endif
   // `ablate` (tuning switch VGEN_TAPGEMM_ABLATE, 0 in production): bit 0 skips the K loop, bit 1 the epilogue's
   // stores — the phase decomposition of a launch (profiles/r02_tapgemm_ablation.json); bit 2 takes the 8-byte
   // store path for 16-bit outputs (A/B of the paired 16-byte stores); bit 3 see lm0 above
@@ -239,6 +274,120 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   // (v3a recomputed rows, bounds and 64-bit products every K-tile: ~700 ALU instructions per wave
   // per K-tile against 32 MFMAs — the loop was issue-bound, not memory- or MFMA-bound.)
   constexpr int NP = LPT + (RBT > 0 ? 1 : 0);
+#ifdef VGEN_BUFDMA
+  unsigned vo[NP];                               // per-lane byte offset of piece j inside its operand's window
+  int so_a = 0, so_w;                            // scalar byte offsets of the NEXT K-tile to issue
+  const int src_cb = (ld_c ^ swz_key<CPR>(ld_r)) * 16;   // byte offset of this lane's source chunk
+  const int wave_row0 = wave * RPI;              // first tile row written by this wave's DMA (+RPP*i)
+  int kt_next = kt_begin;                        // K-tile the offsets currently describe
+  int left;                                      // K-tiles until the A offsets must be regathered
+  const unsigned lda_b = (unsigned)p.lda * 2u, lda2_b = (unsigned)p.lda2 * 2u;     // row strides in bytes (< 2^31)
+  // first source row any live lane of this tile can touch (uniform): window base of the A resource
+  unsigned base_row;
+  if (p.mode == VGEN_TAP_CONV3X3) {
+    const unsigned hw = p.Ho * p.Wo;
+    const unsigned img0 = (unsigned)lm0 / hw;
+    const unsigned oy0 = ((unsigned)lm0 - img0 * hw) / (unsigned)p.Wo;
+    const int y2 = ((int)oy0 * p.stride - p.pad_t + p.crop_t) >> p.ups;
+    base_row = img0 * p.Hi * p.Wi + (unsigned)(y2 > 0 ? y2 : 0) * p.Wi;
+  } else if (p.mode == VGEN_TAP_TEMPORAL3) {
+    base_row = (unsigned)lm0 >= (unsigned)p.S ? (unsigned)lm0 - (unsigned)p.S : 0u;
+  } else {
+    base_row = (unsigned)lm0;
+  }
+  // (uniform values that went through the VALU — the integer divisions — must be pinned to SGPRs: a resource or scalar
+  // offset that instruction selection finds in a VGPR gets a waterfall loop around every DMA instruction)
+  base_row = (unsigned)to_sgpr((int)base_row);
+#ifdef VGEN_BUFCHECK
+  const char* abase_dbg = (const char*)A + (uint64_t)base_row * lda_b;
+  int wt_dbg = kt_begin * WPA;
+#endif
+  __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc((const char*)A + (uint64_t)base_row * lda_b);
+  const __amdgpu_buffer_rsrc_t rsrc_a2 = make_rsrc((const char*)A2 + (uint64_t)(unsigned)lm0 * lda2_b);   // K segment 2
+  // offset of a live row / the out-of-range offset of a row that reads zeros.  The empty asm makes the offset an
+  // unconditional value: left alone, hipcc sinks the multiply into an exec-masked region, and every SCALAR assigned
+  // near it (so_a, left, the resource) then sits behind a divergent join — in a VGPR, with a waterfall loop around
+  // every DMA instruction that takes it as an SGPR operand
+  auto pick = [&](bool ok, unsigned off) __attribute__((always_inline)) -> unsigned {
+    asm volatile("" : "+v"(off));
+    return ok ? off : BUF_OOB;
+  };
+  auto gather_a = [&](int kt) __attribute__((always_inline)) {   // (re)compute vo[0..RA) / so_a for K-tile kt
+    // the scalars first, in straight-line code (selects, no phi behind the per-lane work below)
+    const bool seg1 = kt < T1;
+    const int tap = to_sgpr(seg1 ? kt / cpt1 : 0);
+    const int cch = kt - tap * cpt1;
+    left = to_sgpr(seg1 ? cpt1 - cch : KT - kt + 1);
+    so_a = to_sgpr(seg1 ? cch * BK * 2 : (kt - T1) * BK * 2);
+    if (seg1) {
+      if (p.mode == VGEN_TAP_CONV3X3) {
+        const int d0 = tap / 3, d1 = tap - 3 * d0;
+        const unsigned Hv = (unsigned)((p.Hi << p.ups) - 2 * p.crop_t), Wv = (unsigned)(p.Wi << p.ups);
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+          const int iy = rs[i].a + d0, ix = rs[i].b + d1;
+          const bool ok = ((unsigned)iy < Hv) & ((unsigned)ix < Wv);
+          const unsigned row = (unsigned)rs[i].base + (unsigned)((iy + p.crop_t) >> p.ups) * (unsigned)p.Wi + (unsigned)(ix >> p.ups);
+          vo[i] = pick(ok, (row - base_row) * lda_b + (unsigned)src_cb);
+        }
+      } else if (p.mode == VGEN_TAP_TEMPORAL3) {
+        const int dt_ = tap - 1;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+          const bool ok = (unsigned)(rs[i].a + dt_) < (unsigned)p.F;
+          const unsigned row = (unsigned)(rs[i].base + dt_ * p.S);
+          vo[i] = pick(ok, (row - base_row) * lda_b + (unsigned)src_cb);
+        }
+      } else {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+          const bool ok = rs[i].base >= 0;
+          vo[i] = pick(ok, ((unsigned)rs[i].base - base_row) * lda_b + (unsigned)src_cb);
+        }
+      }
+    } else {
+      rsrc_a = rsrc_a2;
+#ifdef VGEN_BUFCHECK
+      abase_dbg = (const char*)A2 + (uint64_t)(unsigned)lm0 * lda2_b;
+#endif
+#pragma unroll
+      for (int i = 0; i < RA; ++i) {
+        const bool ok = (mvalid >> i) & 1u;
+        vo[i] = pick(ok, (unsigned)(ld_r + RPP * i) * lda2_b + (unsigned)src_cb);
+      }
+    }
+  };
+  gather_a(kt_begin);
+  const unsigned ldw_b = (unsigned)ldw * 2u;
+  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc((const char*)W + (uint64_t)(unsigned)ln0 * ldw_b);
+#ifdef VGEN_BUFCHECK
+  const char* const wbase_dbg = (const char*)W + (uint64_t)(unsigned)ln0 * ldw_b;
+#endif
+  so_w = kt_begin * WPA * BK * 2;
+#pragma unroll
+  for (int i = 0; i < NP - RA; ++i) {
+    const int n = ln0 + ld_r + RPP * i;
+    vo[RA + i] = pick(n < p.N, (unsigned)(ld_r + RPP * i) * ldw_b + (unsigned)src_cb);
+  }
+  auto advance_a = [&]() __attribute__((always_inline)) {   // A offset -> next A K-tile
+    ++kt_next;
+    if (--left == 0) {
+      if (kt_next < KT) gather_a(kt_next);
+    } else {
+      so_a += ROW_BYTES;
+    }
+  };
+  auto advance_w = [&]() __attribute__((always_inline)) {   // W offset -> next W K-tile
+    so_w += ROW_BYTES;
+#ifdef VGEN_BUFCHECK
+    ++wt_dbg;
+#endif
+  };
+  auto advance = [&]() __attribute__((always_inline)) {
+    advance_a();
+    advance_w();
+  };
+#else
   const char* pc[NP];
   const char* const zline = (const char*)g_zeros;
   const int src_cb = (ld_c ^ swz_key<CPR>(ld_r)) * 16;   // byte offset of this lane's source chunk
@@ -323,21 +472,89 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
     advance_a();
     advance_w();
   };
+#endif
   // LDS destination (wave-uniform) of piece j in `stage`
   auto piece_dst = [&](int stage, int j) __attribute__((always_inline)) -> unsigned char* {
     unsigned char* const base = smem + stage * STAGE_BYTES + wave_row0 * ROW_BYTES;
     return j < RA ? base + j * RPP * ROW_BYTES : base + (BM + (j - RA) * RPP) * ROW_BYTES;
   };
+  auto dma = [&](int j, int stage) __attribute__((always_inline)) {   // piece j of the next K-tile -> `stage`
+#ifdef VGEN_BUFCHECK
+    {
+      const char* const ZM = (const char*)1;                    // "this lane reads zeros"
+      const char* exp_;
+      const char* got_;
+      unsigned long long so_ = 0, base_ = 0;
+      if (j < RA) {
+        const int kt = kt_next;
+        if (kt < T1) {
+          const int tap = kt / cpt1, cch = kt - tap * cpt1;
+          bool ok;
+          int64_t row;
+          if (p.mode == VGEN_TAP_CONV3X3) {
+            const int d0 = tap / 3, d1 = tap - 3 * d0;
+            const int Hv = (p.Hi << p.ups) - 2 * p.crop_t, Wv = p.Wi << p.ups;
+            const int iy = rs[j < RA ? j : 0].a + d0, ix = rs[j < RA ? j : 0].b + d1;
+            ok = (iy >= 0) & (iy < Hv) & (ix >= 0) & (ix < Wv);
+            row = (int64_t)rs[j < RA ? j : 0].base + (int64_t)((iy + p.crop_t) >> p.ups) * p.Wi + (ix >> p.ups);
+          } else if (p.mode == VGEN_TAP_TEMPORAL3) {
+            const int f2 = rs[j < RA ? j : 0].a + tap - 1;
+            ok = (f2 >= 0) & (f2 < p.F);
+            row = (int64_t)rs[j < RA ? j : 0].base + (int64_t)(tap - 1) * p.S;
+          } else {
+            ok = rs[j < RA ? j : 0].base >= 0;
+            row = rs[j < RA ? j : 0].base;
+          }
+          exp_ = ok ? (const char*)(A + row * p.lda + cch * BK) + src_cb : ZM;
+        } else {
+          const bool ok = (mvalid >> (j < RA ? j : 0)) & 1u;
+          exp_ = ok ? (const char*)(A2 + (int64_t)((unsigned)lm0 + ld_r + RPP * j) * p.lda2 + (kt - T1) * BK) + src_cb : ZM;
+        }
+        got_ = vo[j] == BUF_OOB ? ZM : abase_dbg + so_a + vo[j];
+        so_ = (unsigned)so_a;
+        base_ = (unsigned long long)abase_dbg;
+      } else {
+        const int n = ln0 + ld_r + RPP * (j - RA);
+        exp_ = n < p.N ? (const char*)(W + (int64_t)n * ldw) + (int64_t)wt_dbg * ROW_BYTES + src_cb : ZM;
+        got_ = vo[j] == BUF_OOB ? ZM : wbase_dbg + so_w + vo[j];
+        so_ = (unsigned)so_w;
+        base_ = (unsigned long long)wbase_dbg;
+      }
+      if (exp_ != got_) {
+        atomicAdd(&g_dbg[15], 1ull);
+        if (atomicCAS(&g_dbg[0], 0ull, 1ull) == 0ull) {
+          g_dbg[1] = (unsigned long long)j;
+          g_dbg[2] = (unsigned long long)(j < RA ? kt_next : wt_dbg);
+          g_dbg[3] = threadIdx.x;
+          g_dbg[4] = blockIdx.x;
+          g_dbg[5] = (unsigned long long)exp_;
+          g_dbg[6] = (unsigned long long)got_;
+          g_dbg[7] = vo[j];
+          g_dbg[8] = so_;
+          g_dbg[9] = base_;
+          g_dbg[10] = (unsigned long long)p.mode;
+          g_dbg[11] = (unsigned long long)(j < RA ? (const char*)A : (const char*)W);
+        }
+      }
+    }
+#endif
+#ifdef VGEN_BUFDMA
+    if (j < RA) blds16(rsrc_a, vo[j], so_a, piece_dst(stage, j));
+    else blds16(rsrc_w, vo[j], so_w, piece_dst(stage, j));
+#else
+    glds16(pc[j], piece_dst(stage, j));
+#endif
+  };
   auto load_tile = [&](int stage) __attribute__((always_inline)) {   // all pieces of the next K-tile back to back
 #pragma unroll
-    for (int j = 0; j < LPT; ++j) glds16(pc[j], piece_dst(stage, j));
-    if (RBT > 0 && w_tail) glds16(pc[NP - 1], piece_dst(stage, NP - 1));
+    for (int j = 0; j < LPT; ++j) dma(j, stage);
+    if (RBT > 0 && w_tail) dma(NP - 1, stage);
     advance();
   };
   auto load_tile_w = [&](int stage) __attribute__((always_inline)) {   // dual-W odd K-tile: the W_lo pieces only
 #pragma unroll
-    for (int j = RA; j < LPT; ++j) glds16(pc[j], piece_dst(stage, j));
-    if (RBT > 0 && w_tail) glds16(pc[NP - 1], piece_dst(stage, NP - 1));
+    for (int j = RA; j < LPT; ++j) dma(j, stage);
+    if (RBT > 0 && w_tail) dma(NP - 1, stage);
     advance_w();
   };
 
@@ -421,8 +638,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
         const int ks = j / (NF * MFH), r = j % (NF * MFH), ni = r / MFH, mi = r % MFH;
         if (i % GRP == 0) {
           if (prefetch) {
-            if (piece < LPT) glds16(pc[piece], piece_dst(stage_pf, piece));
-            else if (RBT > 0 && piece == NP - 1 && w_tail) glds16(pc[NP - 1], piece_dst(stage_pf, NP - 1));
+            if (piece < LPT) dma(piece, stage_pf);
+            else if (RBT > 0 && piece == NP - 1 && w_tail) dma(NP - 1, stage_pf);
           }
           ++piece;
           __builtin_amdgcn_sched_barrier(0);
@@ -472,8 +689,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
       else xf[ks][q - NF] = *(const u32x4*)(bx + (q - NF) * 16 * ROW_BYTES + co);
       if (prefetch && (r % EVERY) == EVERY - 1 && piece < NP) {
         __builtin_amdgcn_sched_barrier(0);
-        if (piece < LPT) glds16(pc[piece], piece_dst(stage_pf, piece));
-        else if (RBT > 0 && w_tail) glds16(pc[NP - 1], piece_dst(stage_pf, NP - 1));
+        if (piece < LPT) dma(piece, stage_pf);
+        else if (RBT > 0 && w_tail) dma(NP - 1, stage_pf);
         ++piece;
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -482,8 +699,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
 #pragma unroll
       for (int j = 0; j < NP; ++j)
         if (j >= piece) {
-          if (j < LPT) glds16(pc[j], piece_dst(stage_pf, j));
-          else if (RBT > 0 && w_tail) glds16(pc[NP - 1], piece_dst(stage_pf, NP - 1));
+          if (j < LPT) dma(j, stage_pf);
+          else if (RBT > 0 && w_tail) dma(NP - 1, stage_pf);
         }
     }
   };
@@ -1222,6 +1439,24 @@ extern "C" int vgen_tapgemm(const vgen_tapgemm_args* args, void* stream) {
   VGEN_REQUIRE(a.M + 256 < (1LL << 31), "tapgemm: M overflows int32 row index");
   VGEN_REQUIRE(a.lda >= 0 && a.lda < (1LL << 30) && a.lda2 >= 0 && a.lda2 < (1LL << 30),
                "tapgemm: lda / lda2 must be in [0, 2^30)");
+#ifdef VGEN_BUFDMA
+  {
+    // per-lane DMA offsets are 32-bit, relative to the first source row of a block's tile: the rows one 256-row tile
+    // can touch, times the row stride, must stay below 2^31
+    int64_t span = 256;
+    if (a.mode == VGEN_TAP_CONV3X3) {
+      const int64_t imgs = a.M / ((int64_t)a.Ho * a.Wo);
+      span = (256 / a.Wo + 3) * (int64_t)a.stride * a.Wi + (256 / ((int64_t)a.Ho * a.Wo) + 1) * (int64_t)a.Hi * a.Wi;
+      if (span > imgs * a.Hi * a.Wi) span = imgs * a.Hi * a.Wi;
+    } else if (a.mode == VGEN_TAP_TEMPORAL3) {
+      span = 256 + 2 * (int64_t)a.S;
+    }
+    const int64_t ldw_eff = a.ldw ? a.ldw : ((int64_t)a.taps * a.C1 + a.C2) * (a.dualw ? 2 : 1);
+    VGEN_REQUIRE(span * a.lda * 2 < (1LL << 31) - (1 << 20) && 256 * a.lda2 * 2 < (1LL << 31) - (1 << 20) &&
+                     256 * ldw_eff * 2 < (1LL << 31) - (1 << 20),
+                 "tapgemm: a tile's source window exceeds 2 GiB (rows %lld x lda %lld)", (long long)span, (long long)a.lda);
+  }
+#endif
   VGEN_REQUIRE(((int64_t)a.taps * a.C1 + a.C2) * (a.dualw ? 4 : 2) <= ZERO_BYTES - 128,
                "tapgemm: K = %lld too long (<= 131008; <= 65504 with dualw)",
                (long long)((int64_t)a.taps * a.C1 + a.C2));
@@ -1258,6 +1493,22 @@ __global__ void stamp_copy_kernel(unsigned long long* dst) {
 }  // namespace
 extern "C" __attribute__((visibility("default"))) int vgen_debug_stamps(void* dev_dst, void* stream) {
   stamp_copy_kernel<<<(STAMP_BLOCKS * 8 * STAMP_SLOTS + 255) / 256, 256, 0, (hipStream_t)stream>>>((unsigned long long*)dev_dst);
+  return (int)hipGetLastError();
+}
+#endif
+
+#ifdef VGEN_BUFCHECK
+namespace {
+__global__ void dbg_copy_kernel(unsigned long long* dst) {
+  const int i = (int)threadIdx.x;
+  if (i < 16) {
+    dst[i] = g_dbg[i];
+    g_dbg[i] = 0;
+  }
+}
+}  // namespace
+extern "C" __attribute__((visibility("default"))) int vgen_debug_dump(void* dev_dst) {
+  dbg_copy_kernel<<<1, 64, 0, 0>>>((unsigned long long*)dev_dst);
   return (int)hipGetLastError();
 }
 #endif
