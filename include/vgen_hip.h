@@ -120,7 +120,7 @@ int vgen_layernorm(const float* x, int64_t M, int32_t d, float eps,
  * The optional second K segment (A2, C2) with identity row mapping fuses the ResBlock's 1x1
  * skip_connection (util.py:885,920) into the out-conv.
  *
- * Constraints: C1 % 64 == 0, C2 % 64 == 0, lda/lda2 % 8 == 0, 16-byte aligned pointers,
+ * Constraints: C1 % 64 == 0, C2 % 64 == 0, lda/lda2 % 8 == 0 and in [0, 2^30), source rows < 2^31, 16-byte aligned pointers,
  * ldw % 8 == 0, K = taps*C1 + C2 <= 131008.  A, A2, W are `dtype` (VGEN_BF16 | VGEN_F16);
  * accumulation is fp32 on the MFMA units.
  *

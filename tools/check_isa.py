@@ -1,0 +1,58 @@
+"""CPU-side ISA audit of tapgemm.hip (hipcc cross-compiles gfx950 without a GPU):  python tools/check_isa.py [-DVGEN_X ...]
+
+For the build with the given defines: register spills per kernel, waterfall loops (a `buffer_load` whose resource /
+scalar offset instruction selection found in a VGPR: v_readfirstlane + s_cbranch_execnz around it) and, for the
+ping-pong 256x160 instantiation, the instruction mix of every loop block (VALU next to the MFMAs is what the K-step
+probe says costs time)."""
+import os, re, subprocess, sys
+from collections import Counter
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from vgen_amd import build as b
+
+defs = [a for a in sys.argv[1:] if a.startswith("-D")]
+out = os.path.join("/tmp", "tapgemm_" + ("_".join(d[2:] for d in defs) or "product") + ".s")
+flags = [f for f in b.FLAGS if f != "-fPIC"] + defs
+r = subprocess.run([b._hipcc()] + flags + ["-S", "--cuda-device-only", os.path.join(b.CSRC, "tapgemm.hip"), "-o", out],
+                   capture_output=True, text=True)
+assert r.returncode == 0, r.stderr[-3000:]
+t = open(out).read()
+vs = [int(x) for x in re.findall(r"\.vgpr_spill_count:\s+(\d+)", t)]
+ss = [int(x) for x in re.findall(r"\.sgpr_spill_count:\s+(\d+)", t)]
+vg = [int(x) for x in re.findall(r"\.vgpr_count:\s+(\d+)", t)]
+print(f"{out}: {len(vs)} kernels, VGPR spills {sum(v > 0 for v in vs)} kernels, max VGPRs {max(vg)}, max SGPR spills {max(ss)}")
+parts = re.split(r"\n(_ZN12_GLOBAL__N_1\w+):", t)
+wf_total = 0
+for i in range(1, len(parts), 2):
+    if "tapgemm_kernel" not in parts[i]:
+        continue
+    body = parts[i + 1].split("s_endpgm")[0]
+    wf = sum(1 for blk in re.split(r"\n\.LBB\d+_\d+:", body)
+             if "v_readfirstlane" in blk and "buffer_load" in blk and "s_cbranch_execnz" in blk)
+    wf_total += wf
+print("waterfall loops around DMA instructions:", wf_total)
+KN = "_ZN12_GLOBAL__N_114tapgemm_kernelI3F16Li256ELi160ELi64ELi4ELi2ELi3ELb1ELb0EEE"
+lines = t.split("\n")
+start = [i for i, l in enumerate(lines) if l.startswith(KN)][0]
+name, blocks, order = None, {}, []
+for l in lines[start:]:
+    ls = l.strip()
+    if ls.startswith("s_endpgm"):
+        break
+    m = re.match(r"(\.LBB\d+_\d+):", ls)
+    if m:
+        name = m.group(1) + (" LOOP" if "Loop" in ls else "")
+        blocks[name] = []
+        order.append(name)
+        continue
+    if name and ls and not ls.startswith((";", ".")):
+        blocks[name].append(ls.split()[0])
+print("loop blocks of the F16 256x160 ping-pong kernel:")
+for n in order:
+    if "LOOP" not in n or not blocks[n]:
+        continue
+    c = Counter(blocks[n])
+    valu = sum(v for k, v in c.items() if k.startswith("v_") and not k.startswith("v_mfma"))
+    salu = sum(v for k, v in c.items() if k.startswith("s_"))
+    keys = {k: v for k, v in c.items() if k.startswith(("v_mfma", "ds_read", "global_load", "buffer_load", "s_barrier", "v_readfirstlane", "v_readlane"))}
+    print(f"  {n:18s} {len(blocks[n]):4d} instr  VALU {valu:3d}  SALU {salu:3d}  {keys}")
