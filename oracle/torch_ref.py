@@ -676,7 +676,8 @@ def lcm_sample_loop(ac, timesteps, noise, model, model_kwargs, guidance_scale, s
 
 # ------------------------------------------------------------------------------------------------
 # OpenCLIP text tower (third-party `open_clip`, not vendored / not pinned by the reference: PARITY UNPINNED against
-# the package itself).  Restated from its published architecture around torch.nn.MultiheadAttention — the module
+# the package itself; pinned instead on the independent implementation of the same architecture that IS installed,
+# transformers' CLIPTextModelWithProjection, on identical weights: tests/test_oracle.py, <= 2e-6).  Restated from its published architecture around torch.nn.MultiheadAttention — the module
 # open_clip's ResidualAttentionBlock wraps — following the reference's call sequence
 # (tools/modules/clip_embedder.py:154-161 encode_with_transformer, :55-64 text_transformer_forward).
 def clip_text_forward(sd, tokens, heads, layer_idx=1, prefix="model."):

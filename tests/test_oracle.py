@@ -151,3 +151,57 @@ def test_abi_emulator_vs_plain_torch_operators():
         emu.attention(spec)
         ref, got = tr.ref_attention(spec)
         assert rel_l2(got, ref) < 2e-6, (name, rel_l2(got, ref))
+
+
+def test_clip_text_oracle_vs_transformers_clip():
+    """f4's third-party dependency (open_clip) is not installed here, so the text tower's restatement cannot be pinned on
+    the package itself.  `transformers` IS installed and ships an independent implementation of the same architecture
+    (CLIPTextModel: pre-LN blocks, causal mask, learned positions, exact GELU when configured so): the oracle run on
+    the SAME weights, re-keyed to open_clip's names, must reproduce its penultimate-layer hidden state after the final
+    LayerNorm (the reference's `layer='penultimate'`, tools/modules/clip_embedder.py:55-64) and the projected
+    end-of-text feature (:163-165) to fp32 rounding."""
+    transformers = pytest.importorskip("transformers")
+    from transformers import CLIPTextConfig, CLIPTextModelWithProjection
+    from oracle import torch_ref
+    torch.manual_seed(0)
+    L, heads, layers, d, vocab = 16, 4, 3, 64, 128
+    cfg = CLIPTextConfig(vocab_size=vocab, hidden_size=d, intermediate_size=4 * d, num_hidden_layers=layers,
+                         num_attention_heads=heads, max_position_embeddings=L, hidden_act="gelu", layer_norm_eps=1e-5,
+                         projection_dim=32, eos_token_id=vocab - 1, pad_token_id=0, bos_token_id=1)
+    hf = CLIPTextModelWithProjection(cfg).eval().float()
+    with torch.no_grad():                                   # the default init is nearly an identity network: liven it up
+        for p_ in hf.parameters():
+            p_.copy_(torch.randn_like(p_) * (0.3 if p_.dim() > 1 else 0.1))
+        for n_, p_ in hf.named_parameters():
+            if "layer_norm" in n_ and n_.endswith("weight"):
+                p_.add_(1.0)
+    tm = hf.text_model
+    sd = {"model.token_embedding.weight": tm.embeddings.token_embedding.weight,
+          "model.positional_embedding": tm.embeddings.position_embedding.weight,
+          "model.ln_final.weight": tm.final_layer_norm.weight, "model.ln_final.bias": tm.final_layer_norm.bias,
+          "model.text_projection": hf.text_projection.weight.t()}
+    for i, lyr in enumerate(tm.encoder.layers):
+        p = f"model.transformer.resblocks.{i}."
+        a = lyr.self_attn
+        sd[p + "attn.in_proj_weight"] = torch.cat([a.q_proj.weight, a.k_proj.weight, a.v_proj.weight])
+        sd[p + "attn.in_proj_bias"] = torch.cat([a.q_proj.bias, a.k_proj.bias, a.v_proj.bias])
+        sd[p + "attn.out_proj.weight"], sd[p + "attn.out_proj.bias"] = a.out_proj.weight, a.out_proj.bias
+        sd[p + "ln_1.weight"], sd[p + "ln_1.bias"] = lyr.layer_norm1.weight, lyr.layer_norm1.bias
+        sd[p + "ln_2.weight"], sd[p + "ln_2.bias"] = lyr.layer_norm2.weight, lyr.layer_norm2.bias
+        sd[p + "mlp.c_fc.weight"], sd[p + "mlp.c_fc.bias"] = lyr.mlp.fc1.weight, lyr.mlp.fc1.bias
+        sd[p + "mlp.c_proj.weight"], sd[p + "mlp.c_proj.bias"] = lyr.mlp.fc2.weight, lyr.mlp.fc2.bias
+    sd = {k: v.detach() for k, v in sd.items()}
+    tokens = torch.randint(2, vocab - 1, (3, L))
+    tokens[:, 0] = 1
+    for b, e in enumerate((5, 11, L - 1)):                  # end-of-text = the highest id, as open_clip's argmax assumes
+        tokens[b, e] = vocab - 1
+        tokens[b, e + 1:] = 0
+    with torch.no_grad():
+        out = hf(input_ids=tokens, output_hidden_states=True)
+        want_pen = tm.final_layer_norm(out.hidden_states[-2])           # penultimate block's output through ln_final
+        want_last = out.last_hidden_state                               # all blocks + ln_final
+        x_pen, _ = torch_ref.clip_text_forward(sd, tokens, heads, layer_idx=1)
+        x_last, xt = torch_ref.clip_text_forward(sd, tokens, heads, layer_idx=0)
+    assert rel_l2(x_pen, want_pen) < 2e-6
+    assert rel_l2(x_last, want_last) < 2e-6
+    assert rel_l2(xt, out.text_embeds) < 2e-6

@@ -9,7 +9,8 @@ the same text path plus `xt = x[eot] @ text_projection`).  The transformer itsel
     ViT-H-14 text: width 1024, 16 heads of 64, 24 layers, context 77, vocab 49408, exact (erf) GELU, eps 1e-5
 
 — so parity is UNPINNED against open_clip itself; the oracle (oracle/torch_ref.py::clip_text_forward) builds the same
-block from `torch.nn.MultiheadAttention`, the module open_clip uses.  Parameter names follow open_clip's `CLIP` text
+block from `torch.nn.MultiheadAttention`, the module open_clip uses, and is pinned on `transformers`' independent
+CLIP text model run on the same weights (tests/test_oracle.py::test_clip_text_oracle_vs_transformers_clip).  Parameter names follow open_clip's `CLIP` text
 branch under the reference's `model.` prefix, so the text keys of a stock checkpoint load (`strict=False` skips the
 `model.visual.*` keys; the image tower is out of scope for this path).
 
