@@ -26,7 +26,6 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from . import lib as L
 from . import ops
 from .ops import Attn, TapGemm
 

@@ -21,7 +21,6 @@ are out of scope; its plms_sample cannot run as shi
 """
 from __future__ import annotations
 
-from typing import Optional
 
 import torch
 

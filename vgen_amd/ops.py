@@ -14,7 +14,7 @@ from __future__ import annotations
 import os
 
 import ctypes as C
-from dataclasses import dataclass, field
+from dataclasses import dataclass
 from typing import Optional
 
 import torch

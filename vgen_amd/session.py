@@ -26,7 +26,7 @@ from __future__ import annotations
 
 import os
 import warnings
-from typing import List, Optional, Sequence
+from typing import Optional, Sequence
 
 import torch
 

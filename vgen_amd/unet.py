@@ -16,9 +16,7 @@ here; `forward` never calls torch compute ops on activations.
 """
 from __future__ import annotations
 
-import math
 import os
-from typing import List, Optional
 
 import torch
 import torch.nn as nn

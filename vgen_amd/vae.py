@@ -15,7 +15,6 @@ from __future__ import annotations
 
 import collections
 import logging
-from typing import Optional
 
 import torch
 import torch.nn as nn
