@@ -3,7 +3,10 @@
 For the build with the given defines: register spills per kernel, waterfall loops (a `buffer_load` whose resource /
 scalar offset instruction selection found in a VGPR: v_readfirstlane + s_cbranch_execnz around it) and, for the
 ping-pong 256x160 instantiation, the instruction mix of every loop block (VALU next to the MFMAs is what the K-step
-probe says costs time)."""
+probe says costs time).  With --uniformity also: LLVM's own uniformity analysis on the optimised IR of that
+instantiation (`opt -passes='print<uniformity>'`) — private-memory allocas that survived (a load from one is divergent
+by definition: r03 found two local arrays tail-merged into a pointer phi that way) and every LDS-DMA call whose resource
+or scalar offset the analysis calls divergent (each becomes a waterfall loop)."""
 import os, re, subprocess, sys
 from collections import Counter
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -56,3 +59,40 @@ for n in order:
     salu = sum(v for k, v in c.items() if k.startswith("s_"))
     keys = {k: v for k, v in c.items() if k.startswith(("v_mfma", "ds_read", "global_load", "buffer_load", "s_barrier", "v_readfirstlane", "v_readlane"))}
     print(f"  {n:18s} {len(blocks[n]):4d} instr  VALU {valu:3d}  SALU {salu:3d}  {keys}")
+
+if "--uniformity" in sys.argv:
+    import tempfile
+    # common.h includes ../../include/vgen_hip.h: mirror that layout
+    td = tempfile.mkdtemp()
+    os.makedirs(os.path.join(td, "a", "b")); os.makedirs(os.path.join(td, "include"))
+    import shutil
+    shutil.copy(os.path.join(ROOT, "include", "vgen_hip.h"), os.path.join(td, "include"))
+    for f in os.listdir(b.CSRC):
+        if os.path.isfile(os.path.join(b.CSRC, f)):
+            shutil.copy(os.path.join(b.CSRC, f), os.path.join(td, "a", "b"))
+    ll = os.path.join(td, "a", "b", "tapgemm.ll")
+    r = subprocess.run([b._hipcc()] + flags + ["-S", "-emit-llvm", "--cuda-device-only", os.path.join(td, "a", "b", "tapgemm.hip"), "-o", ll],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    ir = open(ll).read()
+    print("allocas in the optimised IR (all kernels):", ir.count(" = alloca "))
+    fn = KN + "v17vgen_tapgemm_argsiPfi"
+    i = ir.index("@" + fn + "(")
+    i = ir.rfind("\ndefine", 0, i) + 1
+    j = ir.index("\n}\n", i) + 3
+    decls = "\n".join(l for l in ir.split("\n") if l.startswith(("declare", "attributes", "!", "@", "target", "%")))
+    one = os.path.join(td, "one.ll")
+    open(one, "w").write(decls + "\n" + ir[i:j].replace(" comdat {", " {"))
+    opt = os.path.join(os.path.dirname(os.path.realpath(b._hipcc())), "..", "lib", "llvm", "bin", "opt")
+    if not os.path.exists(opt):
+        opt = "/opt/rocm/lib/llvm/bin/opt"
+    u = subprocess.run([opt, "-passes=print<uniformity>", "-disable-output", one], capture_output=True, text=True).stderr
+    div = set(re.findall(r"DIVERGENT:\s+(%\d+) =", u))
+    calls = [l for l in open(one).read().split("\n") if "raw.ptr.buffer.load.lds(" in l and "call" in l]
+    bad = 0
+    for c in calls:
+        m = re.search(r"\(ptr addrspace\(8\)(?: \w+)* (%\d+), ptr addrspace\(3\)(?: \w+)* [^,]+, i32 16, i32 (%\d+|\d+), i32 (%\d+|\d+),", c)
+        if m and (m.group(1) in div or m.group(3) in div):
+            bad += 1
+    print(f"uniformity: {len(div)} divergent values; {len(calls)} buffer LDS-DMA calls, {bad} with a divergent resource / scalar offset")
+    shutil.rmtree(td)
