@@ -178,12 +178,15 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   constexpr int KS = BK / 32;                   // MFMA k-steps per K-tile
   constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
   constexpr int MF = WTM / 16, NF = WTN / 16;   // fragments per wave
-  constexpr int RA = BM / RPP;                  // A DMA passes per tile (4)
+  constexpr int RAF = BM / RPP;                 // full A DMA passes per tile (4)
+  constexpr int RAT = BM % RPP;                 // tail rows of A (224-row tiles: 32): only waves with wave*RPI < RAT issue
+  constexpr int RA = RAF + (RAT > 0 ? 1 : 0);   // A piece slots per wave (the last one is the tail slot when RAT > 0)
   constexpr int RBF = BN / RPP;                 // full W passes
   constexpr int RBT = BN % RPP;                 // tail rows of W: only waves with wave*RPI < RBT issue
   constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
-  constexpr int LPT = RA + RBF;                 // DMA instructions per wave per tile (+1 with tail)
-  static_assert(BM % RPP == 0 && RBT % RPI == 0, "tile rows must split into whole DMA instructions");
+  constexpr int LPT = RA + RBF;                 // piece slots per wave per tile without the W tail (+1 with it)
+  static_assert(RAT % RPI == 0 && RBT % RPI == 0, "tile rows must split into whole DMA instructions");
+  static_assert(RAT == 0 || (!PP && !DW), "the A-side DMA tail exists in the lock-step K-step only");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -195,6 +198,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   const int lr = lane & 15;  // row within a 16-row fragment
   const int lq = lane >> 4;  // 16-lane group: k-chunk (operands) / 4-row group (C/D)
   const bool w_tail = RBT > 0 && wave * RPI < RBT;
+  const bool a_tail = RAT > 0 && wave * RPI < RAT;   // this wave issues the A tail slot (piece RAF)
 
   // ---- XCD-aware tile renumbering (bijective for any grid size) ----------------------------
   const int tiles_n = (p.N + BN - 1) / BN;
@@ -547,7 +551,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   };
   auto load_tile = [&](int stage) __attribute__((always_inline)) {   // all pieces of the next K-tile back to back
 #pragma unroll
-    for (int j = 0; j < LPT; ++j) dma(j, stage);
+    for (int j = 0; j < LPT; ++j)
+      if (!(RAT > 0 && j == RAF) || a_tail) dma(j, stage);
     if (RBT > 0 && w_tail) dma(NP - 1, stage);
     advance();
   };
@@ -638,8 +643,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
         const int ks = j / (NF * MFH), r = j % (NF * MFH), ni = r / MFH, mi = r % MFH;
         if (i % GRP == 0) {
           if (prefetch) {
-            if (piece < LPT) dma(piece, stage_pf);
-            else if (RBT > 0 && piece == NP - 1 && w_tail) dma(NP - 1, stage_pf);
+            if (piece < LPT) {
+              if (!(RAT > 0 && piece == RAF) || a_tail) dma(piece, stage_pf);
+            } else if (RBT > 0 && piece == NP - 1 && w_tail) {
+              dma(NP - 1, stage_pf);
+            }
           }
           ++piece;
           __builtin_amdgcn_sched_barrier(0);
@@ -735,8 +743,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
     st_l = st_l == STAGES - 1 ? 0 : st_l + 1;
   };
   auto wait_next = [&]() __attribute__((always_inline)) {   // all but the newest tile's pieces have landed
-    if (w_tail) wait_vmcnt<LPT + 1>();
-    else wait_vmcnt<LPT>();
+    constexpr int BASE = LPT - (RAT > 0 ? 1 : 0);           // pieces every wave issues per tile; + the tails it is in
+    const int extra = (a_tail ? 1 : 0) + (w_tail ? 1 : 0);
+    if (RAT > 0 && extra == 2) wait_vmcnt<BASE + 2>();
+    else if (extra == 1) wait_vmcnt<BASE + 1>();
+    else wait_vmcnt<BASE>();
   };
   auto wait_next_w = [&]() __attribute__((always_inline)) {   // ... when the newest tile is a dual-W odd one (W pieces only)
     if (w_tail) wait_vmcnt<LPT - RA + 1>();
@@ -1149,7 +1160,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vgen_tapgemm_a
 // small cost model (microseconds; constants fitted to profiles/r01_*_tapgemm_shapes.json):
 //   cost = rounds(tiles * s / slots) * (ceil(KT / s) * t_ktile + t_tile) + [s > 1] * reduce(s)
 // with KT in 64-element K-steps, slots = 256 ("pp", one block per CU) or 512 ("dual").
-enum Shape { SHAPE_PP = 0, SHAPE_DUAL = 1, SHAPE_PP128 = 2 };
+enum Shape { SHAPE_PP = 0, SHAPE_DUAL = 1, SHAPE_PP128 = 2, SHAPE_DUAL224 = 3 };
+// SHAPE_DUAL224 (experiment, -DVGEN_BM224 only): the dual shape on 224-row tiles (2 x 2 waves of 112 x BN/2, the A side
+// staged in 3.5 DMA passes).  Every row count of the t2v UNet is 7 * 2^k, so 256-row tiles leave the last round over the
+// CUs at most 87.5 % full; 224 = 7 * 32 rows give 256 / 64 / 16 / 4 m-tiles at the four levels.
 
 struct Plan {
   int shape;
@@ -1206,6 +1220,9 @@ Plan make_plan(const vgen_tapgemm_args& a) {
     // the cost model itself only proposes it when neither 128 nor 160 divides N
     bool ok = bn == 64 && a.N % 64 == 0 && (!geglu || a.N % 64 == 0);
     for (int c = 0; c < nc; ++c) ok |= cands[c] == bn;
+#ifdef VGEN_BM224
+    if (shape == SHAPE_DUAL224) return ok && sk == 1 && !a.colstats && !a.dualw;
+#endif
     return ok && shape >= SHAPE_PP && shape <= SHAPE_PP128 && sk >= 1 && sk <= (smax < 1 ? 1 : smax) &&
            !(a.colstats && shape == SHAPE_PP128) && !(a.dualw && shape == SHAPE_DUAL);
   };
@@ -1272,6 +1289,21 @@ Plan make_plan(const vgen_tapgemm_args& a) {
       }
     }
   }
+#ifdef VGEN_BM224
+  // the same dual-shape cost with 224-row tiles: 7/8 of the K-loop work per block, ceil(M / 224) m-tiles
+  if (best.shape == SHAPE_DUAL && best.splitk == 1 && !a.colstats && !a.dualw && force_shape < 0) {
+    const int bi = best.bn == 128 ? 0 : (best.bn == 160 ? 1 : 2);
+    static const double t_d1[3] = {1.10, 1.30, 0.75};
+    static const double t_d2[3] = {2.20, 2.50, 1.40};
+    auto dual_cost = [&](int bm) {
+      const int64_t blocks = ((a.M + bm - 1) / bm) * ((a.N + best.bn - 1) / best.bn);
+      const double f = bm / 256.0;
+      return blocks <= 256 ? KT * t_d1[bi] * f + 10.0 + epi_us
+                           : (double)((blocks + 511) / 512) * (KT * t_d2[bi] * f + 9.0) + 0.5 * epi_us + 1.0;
+    };
+    if (dual_cost(224) < dual_cost(256) - 1e-9) best.shape = SHAPE_DUAL224;
+  }
+#endif
   return best;
 }
 
@@ -1347,6 +1379,15 @@ int dispatch(const vgen_tapgemm_args& a, hipStream_t s) {
       default: return launch<T, 128, 64, 64, 4, 2, 3, true>(a, pl.splitk, s);
     }
   }
+#ifdef VGEN_BM224
+  if (pl.shape == SHAPE_DUAL224) {
+    switch (pl.bn) {
+      case 128: return launch<T, 224, 128, 32, 2, 2, 3, false>(a, pl.splitk, s);
+      case 160: return launch<T, 224, 160, 32, 2, 2, 3, false>(a, pl.splitk, s);
+      default: return launch<T, 224, 64, 32, 2, 2, 3, false>(a, pl.splitk, s);
+    }
+  }
+#endif
   switch (pl.bn) {
     case 128: return launch<T, 256, 128, 32, 2, 2, 3, false>(a, pl.splitk, s);
     case 160: return launch<T, 256, 160, 32, 2, 2, 3, false>(a, pl.splitk, s);
