@@ -16,7 +16,8 @@ AB_ARGS="--steps 20 --warmup 5 --variants= --no-cpu-baseline --no-vae --no-roofl
 VGEN_HIP_LIB=$PWD/vgen_amd/libvgen_hip_stamp.so timeout 60 python tools/stamp_probe.py base 2>&1 | grep -v amdgpu.ids | tail -9
 VGEN_HIP_LIB=$PWD/vgen_amd/libvgen_hip_stamp_buf.so timeout 60 python tools/stamp_probe.py buf 2>&1 | grep -v amdgpu.ids | tail -9
 VGEN_HIP_LIB=$PWD/vgen_amd/libvgen_hip_buf.so timeout 300 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "test_tapgemm" -p no:cacheprovider 2>&1 | tail -4
-# the 224-row dual shape forced on every parity case it is legal for (plan "3,<bn>,1"; illegal cases fall back to the model's plan)
-for bn in 160 128 64; do
-  VGEN_TAPGEMM_PLAN="3,$bn,1" VGEN_HIP_LIB=$PWD/vgen_amd/libvgen_hip_bm224t.so timeout 300 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "test_tapgemm and not dualw" -p no:cacheprovider 2>&1 | tail -2
+# the 224-row shapes forced on every parity case they are legal for (plan "3,<bn>,1" = dual224, "4,320,<split-K>" = the
+# 224 x 320 ping-pong tile; illegal cases fall back to the model's plan)
+for plan in 3,160,1 3,128,1 3,64,1 4,320,1 4,320,2; do
+  VGEN_TAPGEMM_PLAN="$plan" VGEN_HIP_LIB=$PWD/vgen_amd/libvgen_hip_bm224t.so timeout 300 python -m pytest tests/test_gpu_kernels.py -x -q -m gpu -k "test_tapgemm and not dualw" -p no:cacheprovider 2>&1 | tail -2
 done

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
   constexpr int LPT = RA + RBF;                 // piece slots per wave per tile without the W tail (+1 with it)
   static_assert(RAT % RPI == 0 && RBT % RPI == 0, "tile rows must split into whole DMA instructions");
-  static_assert(RAT == 0 || (!PP && !DW), "the A-side DMA tail exists in the lock-step K-step only");
+  static_assert(RAT == 0 || !DW, "no dual-W K-steps on tiles with an A-side DMA tail");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -697,8 +697,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
       else xf[ks][q - NF] = *(const u32x4*)(bx + (q - NF) * 16 * ROW_BYTES + co);
       if (prefetch && (r % EVERY) == EVERY - 1 && piece < NP) {
         __builtin_amdgcn_sched_barrier(0);
-        if (piece < LPT) dma(piece, stage_pf);
-        else if (RBT > 0 && w_tail) dma(NP - 1, stage_pf);
+        if (piece < LPT) {
+          if (!(RAT > 0 && piece == RAF) || a_tail) dma(piece, stage_pf);
+        } else if (RBT > 0 && w_tail) {
+          dma(NP - 1, stage_pf);
+        }
         ++piece;
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -707,8 +710,11 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
 #pragma unroll
       for (int j = 0; j < NP; ++j)
         if (j >= piece) {
-          if (j < LPT) dma(j, stage_pf);
-          else if (RBT > 0 && w_tail) dma(NP - 1, stage_pf);
+          if (j < LPT) {
+            if (!(RAT > 0 && j == RAF) || a_tail) dma(j, stage_pf);
+          } else if (RBT > 0 && w_tail) {
+            dma(NP - 1, stage_pf);
+          }
         }
     }
   };
@@ -1160,10 +1166,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vgen_tapgemm_a
 // small cost model (microseconds; constants fitted to profiles/r01_*_tapgemm_shapes.json):
 //   cost = rounds(tiles * s / slots) * (ceil(KT / s) * t_ktile + t_tile) + [s > 1] * reduce(s)
 // with KT in 64-element K-steps, slots = 256 ("pp", one block per CU) or 512 ("dual").
-enum Shape { SHAPE_PP = 0, SHAPE_DUAL = 1, SHAPE_PP128 = 2, SHAPE_DUAL224 = 3 };
+enum Shape { SHAPE_PP = 0, SHAPE_DUAL = 1, SHAPE_PP128 = 2, SHAPE_DUAL224 = 3, SHAPE_PP224 = 4 };
 // SHAPE_DUAL224 (experiment, -DVGEN_BM224 only): the dual shape on 224-row tiles (2 x 2 waves of 112 x BN/2, the A side
 // staged in 3.5 DMA passes).  Every row count of the t2v UNet is 7 * 2^k, so 256-row tiles leave the last round over the
 // CUs at most 87.5 % full; 224 = 7 * 32 rows give 256 / 64 / 16 / 4 m-tiles at the four levels.
+// SHAPE_PP224 (same switch): the ping-pong schedule on 224 x 320 tiles with 32-element K-tiles, 2 x 4 waves of 112 x 80
+// (35 MFMAs per wave and K-tile against 12 fragment reads; 25 % less operand traffic per FLOP than 256 x 160), for the
+// launches without column statistics whose N is a multiple of 320.  bn = 320 in its plans.
 
 struct Plan {
   int shape;
@@ -1222,6 +1231,8 @@ Plan make_plan(const vgen_tapgemm_args& a) {
     for (int c = 0; c < nc; ++c) ok |= cands[c] == bn;
 #ifdef VGEN_BM224
     if (shape == SHAPE_DUAL224) return ok && sk == 1 && !a.colstats && !a.dualw;
+    if (shape == SHAPE_PP224)
+      return bn == 320 && a.N % 320 == 0 && !geglu && !a.colstats && !a.dualw && sk >= 1 && sk <= (smax < 1 ? 1 : smax);
 #endif
     return ok && shape >= SHAPE_PP && shape <= SHAPE_PP128 && sk >= 1 && sk <= (smax < 1 ? 1 : smax) &&
            !(a.colstats && shape == SHAPE_PP128) && !(a.dualw && shape == SHAPE_DUAL);
@@ -1303,6 +1314,20 @@ Plan make_plan(const vgen_tapgemm_args& a) {
     };
     if (dual_cost(224) < dual_cost(256) - 1e-9) best.shape = SHAPE_DUAL224;
   }
+  // 224 x 320 ping-pong tiles: ~1.9 us per 64 elements of K (a guess from the 256 x 160 figure scaled by the tile area and
+  // the better operand ratios — to be fitted like the others once it has run)
+  if (a.N % 320 == 0 && !geglu && !a.colstats && !a.dualw && force_shape < 0) {
+    const int64_t tiles = ((a.M + 223) / 224) * (a.N / 320);
+    for (int sk = 1; sk <= (smax < 1 ? 1 : smax); ++sk) {
+      const int kts = (KT + sk - 1) / sk;
+      double cost = (double)((tiles * sk + 255) / 256) * (kts * 1.9 + 8.0) + epi_us;
+      if (sk > 1) cost += 5.0 + (double)(sk + 1) * a.M * a.N * 4.0 / 3.0e6;
+      if (cost < best_cost - 1e-9 && (best.shape != SHAPE_DUAL224)) {
+        best_cost = cost;
+        best = Plan{SHAPE_PP224, 320, sk};
+      }
+    }
+  }
 #endif
   return best;
 }
@@ -1380,6 +1405,7 @@ int dispatch(const vgen_tapgemm_args& a, hipStream_t s) {
     }
   }
 #ifdef VGEN_BM224
+  if (pl.shape == SHAPE_PP224) return launch<T, 224, 320, 32, 2, 4, 3, true>(a, pl.splitk, s);
   if (pl.shape == SHAPE_DUAL224) {
     switch (pl.bn) {
       case 128: return launch<T, 224, 128, 32, 2, 2, 3, false>(a, pl.splitk, s);
