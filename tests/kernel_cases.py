@@ -11,9 +11,19 @@ from vgen_amd.ops import Attn, TapGemm
 
 EMU = EmuBackend()
 DTS = {"bf16": torch.bfloat16, "fp16": torch.float16}
-# rel-L2 tolerance of a 16-bit-output kernel vs the fp32-accumulating emulator (one rounding of the
-# output + different summation order); fp32-output kernels are held to 2e-5.
+# rel-L2 tolerances of 16-bit-output kernels; fp32-output kernels are held to 2e-5.
+#   TOL16      a 16-bit output against an UNROUNDED fp32 reference (tests/torch_ops_ref.py, the per-block goldens): one
+#              rounding of the output is 2^-9 / 2^-12 relative at worst, ~1.7e-3 / 2.1e-4 rel-L2 on random data — and the
+#              attention kernels against the emulator, whose P = softmax(S) the kernel rounds to 16 bits before the P.V
+#              MFMAs like every flash kernel (measured on the MI355X, tests/gpu_diag.py: 2.0 - 2.7e-3 bf16, 2.6 - 3.3e-4
+#              fp16; their tests allow 3 x this bound).
+#   TOL16_EMU  a 16-bit output against the emulator of the same arithmetic, for the kernels whose output is ONE rounding of
+#              an fp32 value that differs from the emulator's only by summation order (tap-GEMM incl. GEGLU / dual-W /
+#              split_out, GroupNorm, LayerNorm): the two roundings disagree on a few elements per million — measured
+#              worst cases 3.0e-5 (bf16) / 1.3e-5 (fp16) — so SURVEY's 2e-3 per kernel is met with > 60x to spare and
+#              the bound is set there (r02 held every kernel to the attention bound: VERDICT r02, item 8).
 TOL16 = {"bf16": 4e-3, "fp16": 6e-4}
+TOL16_EMU = {"bf16": 2e-3, "fp16": 3e-4}
 TOL32 = 2e-5
 
 

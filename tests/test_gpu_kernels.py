@@ -1,6 +1,7 @@
 """-m gpu: every C-ABI kernel on the MI355X vs the CPU emulator of the ABI (identical seeded
-inputs).  Tolerances: 16-bit outputs TOL16[dtype] rel-L2 (one output rounding + summation
-order), fp32 outputs 2e-5; the fused CFG+DDIM update must be BIT-EXACT."""
+inputs).  Tolerances (kernel_cases.py): 16-bit outputs TOL16_EMU[dtype] rel-L2 for the single-rounding kernels (SURVEY's
+2e-3 in bf16), TOL16[dtype] where P is rounded inside the kernel or the reference is unrounded fp32, fp32 outputs 2e-5;
+the fused CFG+DDIM update must be BIT-EXACT."""
 import pytest
 import torch
 
@@ -10,29 +11,29 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def _check(res, dtname, out_is_16=None):
+def _check(res, dtname, out_is_16=None, tol16=None):
     for name, st in res.items():
         assert st["finite"], (name, st)
-        tol = kc.TOL16[dtname] if (out_is_16 is None or out_is_16) else kc.TOL32
+        tol = (tol16 or kc.TOL16)[dtname] if (out_is_16 is None or out_is_16) else kc.TOL32
         assert st["rel_l2"] <= tol, (name, st, tol)
 
 
 @pytest.mark.parametrize("dtname", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", kc.GN_CASES, ids=lambda c: "nb%d_S%d_C%d+%d" % c[:4])
 def test_groupnorm(hip_backend, dtname, case):
-    _check(kc.case_groupnorm(hip_backend, DEV, kc.DTS[dtname], *case), dtname)
+    _check(kc.case_groupnorm(hip_backend, DEV, kc.DTS[dtname], *case), dtname, tol16=kc.TOL16_EMU)
 
 
 @pytest.mark.parametrize("dtname", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", kc.GN_CS_CASES, ids=lambda c: "nb%d_S%d_C%d+%d" % c[:4])
 def test_groupnorm_from_colstats(hip_backend, dtname, case):
-    _check(kc.case_groupnorm_cs(hip_backend, DEV, kc.DTS[dtname], *case), dtname)
+    _check(kc.case_groupnorm_cs(hip_backend, DEV, kc.DTS[dtname], *case), dtname, tol16=kc.TOL16_EMU)
 
 
 @pytest.mark.parametrize("dtname", ["bf16", "fp16"])
 @pytest.mark.parametrize("case", kc.LN_CASES, ids=lambda c: "M%d_d%d" % c)
 def test_layernorm(hip_backend, dtname, case):
-    _check(kc.case_layernorm(hip_backend, DEV, kc.DTS[dtname], *case), dtname)
+    _check(kc.case_layernorm(hip_backend, DEV, kc.DTS[dtname], *case), dtname, tol16=kc.TOL16_EMU)
 
 
 _TG = sorted(kc.tapgemm_cases(torch.bfloat16))
@@ -44,7 +45,7 @@ def test_tapgemm(hip_backend, dtname, name):
     spec = kc.tapgemm_cases(kc.DTS[dtname])[name]
     res = kc.case_tapgemm(hip_backend, DEV, spec)
     cs = res.pop("colstats", None)
-    _check(res, dtname, out_is_16=spec.out_dtype != torch.float32)
+    _check(res, dtname, out_is_16=spec.out_dtype != torch.float32, tol16=kc.TOL16_EMU)
     if cs is not None:
         assert cs["finite"] and cs["rel_l2"] <= 2e-5, cs
 
@@ -61,7 +62,7 @@ def test_tapgemm_dualw(hip_backend, dtname, name):
     spec = kc.tapgemm_dw_cases(kc.DTS[dtname])[name]
     res = kc.case_tapgemm(hip_backend, DEV, spec)
     cs = res.pop("colstats", None)
-    _check(res, dtname, out_is_16=spec.out_dtype != torch.float32)
+    _check(res, dtname, out_is_16=spec.out_dtype != torch.float32, tol16=kc.TOL16_EMU)
     if cs is not None:
         assert cs["finite"] and cs["rel_l2"] <= 2e-5, cs
     out = hip_backend.tapgemm(kc._clone_spec(spec, DEV)).float().cpu()
