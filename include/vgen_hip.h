@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define VGEN_ABI_VERSION 4
+#define VGEN_ABI_VERSION 5
 
 enum { VGEN_BF16 = 0, VGEN_F16 = 1, VGEN_F32 = 2 };
 
@@ -339,11 +339,12 @@ int vgen_gaussian_sample(const float* moments, const float* noise, int64_t nimg,
  *   eps = (xt - alpha*x0)/sigma (optional).  coef = [B][2] fp32 (alpha, sigma).
  * vgen_lincomb4 : out = ca*a + cb*b + cc*c + cd*d (NULL operands skipped, fp32, no contraction):
  *   scalings around the model call of DPM-Solver++(2M).
- * vgen_dpmpp2m_sde_step: ONE solver update (diffusion_gauss.py:126-139), every intermediate rounded where the
- *   reference's three tensor statements round:  r = ca*x + cb*denoised;  old_denoised != NULL (2M correction, :131-136):
- *   r = r + cc*denoised - cc*old_denoised;  noise != NULL (SDE term, :138-139): r = r + cn*noise.  ca = sigma_next /
- *   sigma * exp(-eta h), cb = -expm1(-h - eta h), cc = midpoint / Heun coefficient / r, cn = sigma_next *
- *   sqrt(-expm1(-2 eta h)) * s_noise — host scalars in the reference's own expressions.
+ * vgen_dpmpp2m_sde_step: ONE solver update (diffusion_gauss.py:122-139), every intermediate rounded where the
+ *   reference's three tensor statements round (ABI 5: r03's form followed three lincomb4 calls instead, 1-2 ulp off):
+ *   r = ca*x + cb*denoised;  old_denoised != NULL (2M correction, :126-134): r = r + cc*(denoised - old_denoised), the
+ *   difference rounded first;  noise != NULL (SDE term, :136-139): r = r + ((noise*cn1)*cn2)*cn3.  ca = sigma_next /
+ *   sigma * exp(-eta h), cb = -expm1(-h - eta h), cc = midpoint / Heun coefficient * (1 / r), cn1 = sigma_next, cn2 =
+ *   sqrt(-expm1(-2 eta h)), cn3 = s_noise — host scalars in the reference's own expressions.
  */
 /* FreeU-style skip filter of UNetSD_SR600 (unet_sr600.py:30-49, 276-287), on rows [nimg*H*W, C] fp32:
  * Fourier_filter(x, threshold=1, scale) multiplies the 2x2 block of centred-spectrum bins
@@ -406,7 +407,8 @@ int vgen_gauss_x0(const float* xt, const float* out, const void* ws, float resca
 int vgen_lincomb4(const float* a, const float* b, const float* c, const float* d, float ca, float cb,
                   float cc, float cd, float* out, int64_t n, void* stream);
 int vgen_dpmpp2m_sde_step(const float* x, const float* denoised, const float* old_denoised, const float* noise,
-                          float ca, float cb, float cc, float cn, float* out, int64_t n, void* stream);
+                          float ca, float cb, float cc, float cn1, float cn2, float cn3, float* out, int64_t n,
+                          void* stream);
 
 #ifdef __cplusplus
 }

@@ -359,12 +359,14 @@ class EmuBackend:
         return table.index_select(0, idx.clamp(0, table.shape[0] - 1))
 
     def dpmpp2m_sde_step(self, x, denoised, old, noise, ca, cb, cc, cn):
-        # vgen_dpmpp2m_sde_step: the three statements of diffusion_gauss.py:126-139, each rounded like a lincomb4
-        r = self.lincomb4(x, denoised, None, None, ca, cb, 0, 0)
+        # vgen_dpmpp2m_sde_step: the three tensor statements of diffusion_gauss.py:122-139 in the reference's own
+        # rounding order (0-dim scalars folded on the host, tensor products rounded one by one)
+        f = lambda v: torch.tensor(v, dtype=torch.float32)
+        r = f(ca) * x + f(cb) * denoised
         if old is not None:
-            r = self.lincomb4(r, denoised, old, None, 1.0, cc, -cc, 0)
+            r = r + f(cc) * (denoised - old)
         if noise is not None:
-            r = self.lincomb4(r, noise, None, None, 1.0, cn, 0, 0)
+            r = r + noise * f(cn[0]) * f(cn[1]) * f(cn[2])
         return r
 
     def gaussian_sample(self, moments, noise, nimg, zc, HW, scale):

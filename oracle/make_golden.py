@@ -287,6 +287,99 @@ def make_i2vgen_full(R):
                os.path.join(GOLD, "unet_i2vgen_full.pt"))
 
 
+def _sub(out):
+    """full-size outputs are stored sub-sampled (frames ::2, rows / cols ::4) with their norm"""
+    return out[:, :, ::2, ::4, ::4].contiguous()
+
+
+def make_t2v_extra(R):
+    """r04: two more full-size t2v fixtures next to unet_t2v_full.pt (seed 0, Gaussian weights, t = 981) so that the 1e-3
+    claim of precision="mixed" does not rest on one (weights, input, t) triple:
+    unet_t2v_full_b.pt — a SECOND weight seed with heavy-tailed (Student-t, nu = 4) matrices, t = 741;
+    unet_t2v_full_c.pt — the headline weights at a mid-trajectory t = 501 on another input."""
+    import time
+    ref = R["MODEL"].build(dict(type="UNetSD_T2VBase", **UNET_T2V)).eval()
+    shapes = torch_ref.shapes_of(ref)
+    for tag, seed, recipe, input_seed, tval in (("b", 1, "student4", 8890, 741), ("c", 0, "gauss", 8891, 501)):
+        ref.load_state_dict(torch_ref.synth_state_dict(shapes, seed=seed, recipe=recipe), strict=True)
+        g = torch.Generator("cpu").manual_seed(input_seed)
+        x = torch.randn(1, 4, 16, 32, 56, generator=g)
+        y = torch.randn(1, 77, 1024, generator=g)
+        t = torch.tensor([tval])
+        t0 = time.time()
+        with torch.no_grad():
+            out = ref(x, t, y=y)
+        print("unet_t2v_full_%s: %.1f s, std %.4f" % (tag, time.time() - t0, float(out.std())))
+        torch.save(dict(cfg=UNET_T2V, seed=seed, recipe=recipe, shapes=shapes, input_seed=input_seed, t=t, out=out,
+                        out_norm=float(out.norm())), os.path.join(GOLD, "unet_t2v_full_%s.pt" % tag))
+
+
+def make_videolcm_full(R):
+    """FULL-WIDTH UNetSD_VideoLCM (text-only composition, configs/videolcm_t2v_infer.yaml:67) at BASELINE config 4's
+    latent [1,4,16,32,56], float timestep as the LCM engine passes it (unet_videolcm.py:541-784)."""
+    import time
+    import types
+    cfgm = dict(UNET_T2V, concat_dim=8, num_tokens=4, training=False)
+    cfg = types.SimpleNamespace(video_compositions=["text"], resolution=[448, 256])
+    ref = R["MODEL"].build(dict(type="UNetSD_VideoLCM", config=cfg, **cfgm)).eval()
+    shapes = torch_ref.shapes_of(ref)
+    ref.load_state_dict(torch_ref.synth_state_dict(shapes, seed=0), strict=True)
+    g = torch.Generator("cpu").manual_seed(8893)
+    x = torch.randn(1, 4, 16, 32, 56, generator=g)
+    y = torch.randn(1, 77, 1024, generator=g)
+    t = torch.tensor([759.0])
+    t0 = time.time()
+    with torch.no_grad():
+        out = ref(x, t, y=y)
+    print("unet_videolcm_full: %.1f s, std %.4f" % (time.time() - t0, float(out.std())))
+    torch.save(dict(cfg=cfgm, comps=["text"], resolution=[448, 256], seed=0, shapes=shapes, input_seed=8893, t=t,
+                    out=out, out_norm=float(out.norm())), os.path.join(GOLD, "unet_videolcm_full.pt"))
+
+
+def make_tft2v_full(R):
+    """FULL-WIDTH UNetSD_TFT2V with the compositions of configs/tft2v_t2v_infer.yaml:65 (['text', 'image']) at BASELINE
+    config 5's first-stage latent [1,4,16,64,112] (16 x 896 x 512; unet_tf2tv.py:538-777): 39 TFLOP on the CPU."""
+    import time
+    import types
+    cfgm = dict(UNET_T2V, concat_dim=8, num_tokens=4, training=False)
+    cfg = types.SimpleNamespace(video_compositions=["text", "image"], resolution=[896, 512])
+    ref = R["MODEL"].build(dict(type="UNetSD_TFT2V", config=cfg, **cfgm)).eval()
+    shapes = torch_ref.shapes_of(ref)
+    ref.load_state_dict(torch_ref.synth_state_dict(shapes, seed=0), strict=True)
+    g = torch.Generator("cpu").manual_seed(8894)
+    x = torch.randn(1, 4, 16, 64, 112, generator=g)
+    y = torch.randn(1, 77, 1024, generator=g)
+    image = torch.randn(1, 1, 1024, generator=g)
+    t = torch.tensor([401])
+    t0 = time.time()
+    with torch.no_grad():
+        out = ref(x, t, y=y, image=image)
+    print("unet_tft2v_full: %.1f s, std %.4f" % (time.time() - t0, float(out.std())))
+    torch.save(dict(cfg=cfgm, comps=["text", "image"], resolution=[896, 512], seed=0, shapes=shapes, input_seed=8894,
+                    t=t, out_sub=_sub(out), out_norm=float(out.norm())), os.path.join(GOLD, "unet_tft2v_full.pt"))
+
+
+def make_sr600_full(R):
+    """FULL-WIDTH UNetSD_SR600 at BASELINE config 5's second-stage latent [1,4,32,90,160] (32 x 1280 x 720;
+    unet_sr600.py:220-299): 90 -> 45 -> 23 -> 12 rows, 14 400-token spatial attention over 32 frames, FreeU +
+    Fourier skip filter; 186 TFLOP on the CPU."""
+    import time
+    cfgm = dict(UNET_T2V, use_scale_shift_norm=True, inpainting=True)
+    cfgm.pop("use_fps_condition", None)
+    ref = R["MODEL"].build(dict(type="UNetSD_SR600", **cfgm)).eval()
+    shapes = torch_ref.shapes_of(ref)
+    ref.load_state_dict(torch_ref.synth_state_dict(shapes, seed=0), strict=True)
+    g = torch.Generator("cpu").manual_seed(8895)
+    x = torch.randn(1, 4, 32, 90, 160, generator=g)
+    y = torch.randn(1, 77, 1024, generator=g)
+    t = torch.tensor([699])
+    t0 = time.time()
+    with _no_cuda(), torch.no_grad():
+        out = ref(x.clone(), t, y)
+    print("unet_sr600_full: %.1f s, std %.4f" % (time.time() - t0, float(out.std())))
+    torch.save(dict(cfg=cfgm, seed=0, shapes=shapes, input_seed=8895, t=t, out_sub=_sub(out),
+                    out_norm=float(out.norm())), os.path.join(GOLD, "unet_sr600_full.pt"))
+
 
 def _no_cuda():
     """context: the reference hard-codes .cuda() in a few places (unet_i2vgen.py:284, unet_sr600.py:38)"""
@@ -601,6 +694,11 @@ def main():
         return
     if args.only == "i2vgen_full":
         make_i2vgen_full(R)
+        return
+    extra = dict(t2v_extra=make_t2v_extra, videolcm_full=make_videolcm_full, tft2v_full=make_tft2v_full,
+                 sr600_full=make_sr600_full)
+    if args.only in extra:
+        extra[args.only](R)
         return
     torch.manual_seed(0)
 

@@ -22,13 +22,13 @@ import torch.nn.functional as F
 # ------------------------------------------------------------------------------------------
 
 
-def synth_state_dict(shapes: dict, seed: int = 0, gain: float = 0.8) -> dict:
+def synth_state_dict(shapes: dict, seed: int = 0, gain: float = 0.8, recipe: str = "gauss") -> dict:
     """Seeded re-randomisation of EVERY parameter (the reference zero-initialises the ResBlock
     out-conv, temporal conv4, proj_out, head conv — util.py:873-875,1683-1684,351,1229,
     unet_t2v.py:208 — which would make a parity check vacuous; SURVEY.md §8c "Trap").
     The recipe lives in vgen_amd/synth.py (bench.py times the very weights the golden fixtures were made with)."""
     from vgen_amd.synth import seeded_state_dict
-    return seeded_state_dict(shapes, seed, gain)
+    return seeded_state_dict(shapes, seed, gain, recipe)
 
 
 def shapes_of(module) -> dict:

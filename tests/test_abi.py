@@ -96,3 +96,18 @@ def test_hot_kernels_have_no_register_spills(tmp_path):
         names = re.findall(r"\.name:\s+(\S+)", txt)
         spills = [int(v) for v in re.findall(r"\.vgpr_spill_count:\s+(\d+)", txt)]
         assert len(spills) >= 6 and all(s == 0 for s in spills), list(zip(names, spills))
+        if src == "tapgemm.hip":
+            # "product kernels instruction-identical" must be something a test enforces.  The instruction
+            # stream of the product build is pinned to a committed fingerprint: whoever edits the kernel refreshes it with
+            # `python tools/check_isa.py --update-hash` — and reruns the GPU parity cases on that build in the same change.
+            import hashlib
+            keep = []
+            for l in txt.split("\n"):
+                l = l.split(";")[0].strip()
+                if not l or l.startswith(".") or l.endswith(":") or l.startswith("__hip_cuid"):
+                    continue
+                keep.append(" ".join(l.split()))
+            fp = hashlib.sha256("\n".join(keep).encode()).hexdigest()
+            want = open(os.path.join(os.path.dirname(__file__), "golden", "tapgemm_isa.sha256")).read().strip()
+            assert fp == want, ("tap-GEMM product ISA changed: refresh tests/golden/tapgemm_isa.sha256 (tools/check_isa.py "
+                                "--update-hash) and rerun the GPU kernel parity cases", fp)

@@ -153,13 +153,21 @@ def test_gauss_kernels_gpu(hip_backend):
     r = emu.lincomb4(xt, y, u, None, 0.3, -1.7, 0.25, 0)
     rg = hip_backend.lincomb4(xt.cuda(), y.cuda(), u.cuda(), None, 0.3, -1.7, 0.25, 0)
     assert torch.equal(rg.cpu(), r)
-    # the fused DPM-Solver++(2M) SDE update: bit-equal to the three-statement sequence, with and without the 2M
-    # correction / the noise term
+    # the fused DPM-Solver++(2M) SDE update: bit-equal to the reference's three tensor statements in their own rounding
+    # order (diffusion_gauss.py:122-139), with and without the 2M correction / the noise term
     nz = torch.randn(3, 4, 4, 16, 8, generator=g)
     for old, noise in ((u, nz), (None, nz), (u, None), (None, None)):
-        r = emu.dpmpp2m_sde_step(xt, y, old, noise, 0.83, 0.41, 0.27, 0.66)
+        cn = (0.66, 0.73, 1.0)
+        r = emu.dpmpp2m_sde_step(xt, y, old, noise, 0.83, 0.41, 0.27, cn)
+        sc = lambda v: torch.tensor(v, dtype=torch.float32)        # 0-dim fp32 tensors, as in the reference
+        ref = sc(0.83) * xt + sc(0.41) * y
+        if old is not None:
+            ref = ref + sc(0.27) * (y - old)
+        if noise is not None:
+            ref = ref + noise * sc(0.66) * sc(0.73) * 1.0
+        assert torch.equal(r, ref)
         rg = hip_backend.dpmpp2m_sde_step(xt.cuda(), y.cuda(), None if old is None else old.cuda(),
-                                          None if noise is None else noise.cuda(), 0.83, 0.41, 0.27, 0.66)
+                                          None if noise is None else noise.cuda(), 0.83, 0.41, 0.27, cn)
         assert torch.equal(rg.cpu(), r)
 
 

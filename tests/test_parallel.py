@@ -304,14 +304,29 @@ def test_vae_decode_video_frame_sharded_world2():
 def test_slice_kwargs_only_touches_per_prompt_keys():
     from vgen_amd.parallel import _slice_kwargs
     idx = torch.tensor([1])
-    kw = dict(y=torch.arange(6.).view(2, 3), shared=torch.arange(4.).view(2, 2), fps=torch.tensor([8]), flag=True)
+    kw = dict(y=torch.arange(6.).view(2, 3), shared=torch.arange(12.).view(3, 4), fps=torch.tensor([8]), flag=True,
+              t_w=torch.tensor([3.0, 7.0]))
     out = _slice_kwargs(kw, idx, 2)
     assert torch.equal(out["y"], kw["y"][1:2])
-    assert out["shared"] is kw["shared"]                              # leading dim == P by accident: not a per-prompt key
+    assert out["shared"] is kw["shared"]                              # unknown name, leading dim != P: passed through
     assert out["fps"].shape == (1,) and int(out["fps"][0]) == 8       # broadcast row expanded to the local prompts
     assert out["flag"] is True
+    assert torch.equal(out["t_w"], torch.tensor([7.0]))               # VideoLCM's guidance weight [B] (unet_videolcm.py:544)
     with pytest.raises(ValueError):
         _slice_kwargs(dict(y=torch.zeros(3, 2)), idx, 2)
+    # an unknown name whose leading dim == P while a subset of the prompts runs is ambiguous -> raises ...
+    amb = dict(y=kw["y"], custom=torch.arange(4.).view(2, 2))
+    with pytest.raises(ValueError, match="register_per_prompt_keys"):
+        _slice_kwargs(amb, idx, 2)
+    # ... unless every prompt is local (nothing to slice), or the caller declares it per-prompt
+    assert _slice_kwargs(amb, torch.tensor([0, 1]), 2)["custom"] is amb["custom"]
+    import vgen_amd.parallel as par
+    saved = par.PER_PROMPT_KEYS
+    try:
+        par.register_per_prompt_keys("custom")
+        assert torch.equal(_slice_kwargs(amb, idx, 2)["custom"], amb["custom"][1:2])
+    finally:
+        par.PER_PROMPT_KEYS = saved
 
 
 def test_session_key_sees_tensors_inside_containers():

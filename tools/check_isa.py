@@ -7,7 +7,7 @@ probe says costs time).  With --uniformity also: LLVM's own uniformi
 instantiation (`opt -passes='print<uniformity>'`) — private-memory allocas that survived (a load from one is divergent
 by definition: r03 found two local arrays tail-merged into a pointer phi that way) and every LDS-DMA call whose resource
 or scalar offset the analysis calls divergent (each becomes a waterfall loop)."""
-import os, re, subprocess, sys
+import hashlib, os, re, subprocess, sys
 from collections import Counter
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -20,6 +20,28 @@ r = subprocess.run([b._hipcc()] + flags + ["-S", "--cuda-device-only", os.path.j
                    capture_output=True, text=True)
 assert r.returncode == 0, r.stderr[-3000:]
 t = open(out).read()
+
+
+def isa_fingerprint(asm_text):
+    """sha256 over the instruction stream of every kernel (labels, directives, comments and the per-compilation
+    __hip_cuid symbol dropped): two sources with the same fingerprint ARE the same machine code.  The product value is
+    committed in tests/golden/tapgemm_isa.sha256 and checked by tests/test_abi.py — a kernel edit has to refresh it
+    (`python tools/check_isa.py --update-hash`) and, with it, rerun the GPU parity cases."""
+    keep = []
+    for l in asm_text.split("\n"):
+        l = l.split(";")[0].strip()
+        if not l or l.startswith(".") or l.endswith(":") or l.startswith("__hip_cuid"):
+            continue
+        keep.append(" ".join(l.split()))
+    return hashlib.sha256("\n".join(keep).encode()).hexdigest(), len(keep)
+
+
+fp, nins = isa_fingerprint(t)
+HASH_FILE = os.path.join(ROOT, "tests", "golden", "tapgemm_isa.sha256")
+print(f"ISA fingerprint: {fp} ({nins} instructions)")
+if "--update-hash" in sys.argv and not defs:
+    open(HASH_FILE, "w").write(fp + "\n")
+    print("written to", HASH_FILE)
 vs = [int(x) for x in re.findall(r"\.vgpr_spill_count:\s+(\d+)", t)]
 ss = [int(x) for x in re.findall(r"\.sgpr_spill_count:\s+(\d+)", t)]
 vg = [int(x) for x in re.findall(r"\.vgpr_count:\s+(\d+)", t)]

@@ -569,28 +569,31 @@ __global__ __launch_bounds__(256) void lincomb4_kernel(const float* __restrict__
 }
 
 // One DPM-Solver++(2M) SDE update (vgen_dpmpp2m_sde_step): the exponential-integrator step, the 2M midpoint / Heun
-// correction and the Brownian-noise injection in one pass, every intermediate rounded to fp32 exactly where the
-// reference's three tensor statements round (diffusion_gauss.py:126-139) — bit-identical to three vgen_lincomb4 calls.
+// correction and the Brownian-noise injection in one pass.  Every intermediate is rounded to fp32 where the reference's
+// three tensor statements round (diffusion_gauss.py:122-139; r04 — ADVICE r03: the first version was bit-identical to three
+// lincomb4 calls instead, 1-2 ulp off): the 2M term multiplies the ROUNDED difference (denoised - old_denoised) by the
+// host scalar c * (1 / r), the noise is scaled by sigma_next, sqrt(-expm1(-2 eta h)) and s_noise one after the other.
 __global__ __launch_bounds__(256) void dpmpp2m_sde_step_kernel(const float* __restrict__ x, const float* __restrict__ den,
                                                                const float* __restrict__ old, const float* __restrict__ nz,
-                                                               float ca, float cb, float cc, float cn,
+                                                               float ca, float cb, float cc, float cn1, float cn2, float cn3,
                                                                float* __restrict__ out, int64_t n) {
 #pragma clang fp contract(off)
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const float d = den[i];
-  float r = ca * x[i];
-  r = r + cb * d;                               // x = sigma_next / sigma * exp(-eta h) * x + (-h - eta h).expm1().neg() * denoised
-  if (old) {                                    // x = x + c * (1 / r) * (denoised - old_denoised), as  1 * x + cc * den + (-cc) * old
-    float q = 1.0f * r;
-    q = q + cc * d;
-    q = q + (-cc) * old[i];
-    r = q;
+  const float p0 = ca * x[i];
+  const float p1 = cb * d;
+  float r = p0 + p1;                            // x = sigma_next / sigma * exp(-eta h) * x + (-h - eta h).expm1().neg() * denoised
+  if (old) {                                    // x = x + c * (1 / r) * (denoised - old_denoised)
+    const float df = d - old[i];
+    const float q = cc * df;
+    r = r + q;
   }
   if (nz) {                                     // x = x + noise * sigma_next * sqrt(-expm1(-2 eta h)) * s_noise
-    float q = 1.0f * r;
-    q = q + cn * nz[i];
-    r = q;
+    float q = nz[i] * cn1;
+    q = q * cn2;
+    q = q * cn3;
+    r = r + q;
   }
   out[i] = r;
 }
@@ -645,13 +648,14 @@ extern "C" int vgen_gather_rows_f32(const float* table, int64_t nrows_table, int
 }
 
 extern "C" int vgen_dpmpp2m_sde_step(const float* x, const float* denoised, const float* old_denoised, const float* noise,
-                                     float ca, float cb, float cc, float cn, float* out, int64_t n, void* stream) {
+                                     float ca, float cb, float cc, float cn1, float cn2, float cn3, float* out, int64_t n,
+                                     void* stream) {
   VGEN_REQUIRE(x != nullptr && denoised != nullptr && out != nullptr, "dpmpp2m_sde_step: x/denoised/out null");
   if (n <= 0) return 0;
   const int64_t grid = (n + 255) / 256;
   VGEN_REQUIRE(grid < (1LL << 31), "dpmpp2m_sde_step: too large");
   hipLaunchKernelGGL(dpmpp2m_sde_step_kernel, dim3((unsigned)grid), dim3(256), 0, (hipStream_t)stream, x, denoised,
-                     old_denoised, noise, ca, cb, cc, cn, out, n);
+                     old_denoised, noise, ca, cb, cc, cn1, cn2, cn3, out, n);
   return vgen_check_launch("dpmpp2m_sde_step");
 }
 

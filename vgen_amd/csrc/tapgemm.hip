@@ -72,61 +72,12 @@ __device__ __attribute__((aligned(128))) unsigned char g_zeros[ZERO_BYTES];
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-// -DVGEN_STAMP (probe build only, tools/stamp_probe.py): every wave of the first 64 blocks sums the s_memtime cycles it
-// spends in each segment of a ping-pong K-step into 12 counters and stores them after the K loop (no store inside the
-// loop: gfx950 counts stores in vmcnt).  Segments: 0 read phase issued + fragments landed, 1 counted vmcnt wait,
-// 2 barrier before the matrix phase, 3 matrix phase issued, 4 pointer step + barrier after it; 5-9 the same for the odd
-// step of a dual-W pair; 10 = K-steps, 11 = whole loop.
-#ifdef VGEN_STAMP
-constexpr int STAMP_SLOTS = 12, STAMP_BLOCKS = 64;
-__device__ unsigned long long g_stamp[STAMP_BLOCKS * 8 * STAMP_SLOTS];
-#define VGEN_STAMP_AT(k)                                         \
-  do {                                                           \
-    __builtin_amdgcn_sched_barrier(0);                           \
-    const unsigned long long t_ = __builtin_amdgcn_s_memtime();  \
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           \
-    st_acc[k] += t_ - st_prev;                                   \
-    st_prev = t_;                                                \
-    __builtin_amdgcn_sched_barrier(0);                           \
-  } while (0)
-#else
-#define VGEN_STAMP_AT(k)
-#endif
 
 __device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_base) {
   // 64 lanes x 16 B -> LDS [lds_wave_base + lane*16]; the LDS base must be wave-uniform
   __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
-#ifdef VGEN_BUFCHECK
-// self-checking probe build of the BUFDMA experiment: every DMA issue recomputes the address the pointer path would
-// use from first principles and records the first disagreement (tools/probes/tapgemm_ab.cpp prints it)
-__device__ unsigned long long g_dbg[16];
-#endif
-#ifdef VGEN_BUFDMA
-// experiment: the same DMA as `buffer_load_dwordx4 ... offen lds` — 128-bit resource + scalar byte offset in SGPRs, one
-// 32-bit per-lane offset: the per-K-tile pointer step becomes one s_add per operand instead of a 64-bit VALU add per
-// piece, and a row that must read zeros is an out-of-range offset (no zero region, no select)
-constexpr unsigned BUF_OOB = 0x80000000u;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base) {
-  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, 0x7fffffff, 0x00020000);
-}
-// A wave-uniform value that went through the VALU (an integer division) pinned to an SGPR.  Inline asm on purpose:
-// hipcc folds __builtin_amdgcn_readfirstlane of a value its IR analysis calls uniform, instruction selection then finds
-// the value in a VGPR anyway and wraps every buffer_load that takes it as a scalar operand in a waterfall loop.
-// The hazard recognizer does not look inside inline asm, so both hazards are padded by hand: gfx950 needs a wait state
-// between a VALU write of a VGPR and a v_readfirstlane of it (hipcc puts `s_nop 0` there itself; without it the first
-// self-checking run, tools/probes/tapgemm_ab.cpp, read STALE lane-0 contents: profiles/r03o_bufdma_selfcheck.txt), and
-// five between a VALU write of an SGPR and a VMEM instruction that reads it.
-__device__ __forceinline__ int to_sgpr(int x) {
-  int r;
-  asm volatile("s_nop 1\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(r) : "v"(x));
-  return r;
-}
-__device__ __forceinline__ void blds16(__amdgpu_buffer_rsrc_t r, unsigned voff, int soff, unsigned char* lds_wave_base) {
-  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr_t)lds_wave_base, 16, (int)voff, soff, 0, 0);
-}
-#endif
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -178,15 +129,12 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   constexpr int KS = BK / 32;                   // MFMA k-steps per K-tile
   constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
   constexpr int MF = WTM / 16, NF = WTN / 16;   // fragments per wave
-  constexpr int RAF = BM / RPP;                 // full A DMA passes per tile (4)
-  constexpr int RAT = BM % RPP;                 // tail rows of A (224-row tiles: 32): only waves with wave*RPI < RAT issue
-  constexpr int RA = RAF + (RAT > 0 ? 1 : 0);   // A piece slots per wave (the last one is the tail slot when RAT > 0)
+  constexpr int RA = BM / RPP;                  // A DMA passes per tile (4)
   constexpr int RBF = BN / RPP;                 // full W passes
   constexpr int RBT = BN % RPP;                 // tail rows of W: only waves with wave*RPI < RBT issue
   constexpr int STAGE_BYTES = (BM + BN) * ROW_BYTES;
   constexpr int LPT = RA + RBF;                 // piece slots per wave per tile without the W tail (+1 with it)
-  static_assert(RAT % RPI == 0 && RBT % RPI == 0, "tile rows must split into whole DMA instructions");
-  static_assert(RAT == 0 || !DW, "no dual-W K-steps on tiles with an A-side DMA tail");
+  static_assert(BM % RPP == 0 && RBT % RPI == 0, "tile rows must split into whole DMA instructions");
 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
@@ -198,7 +146,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   const int lr = lane & 15;  // row within a 16-row fragment
   const int lq = lane >> 4;  // 16-lane group: k-chunk (operands) / 4-row group (C/D)
   const bool w_tail = RBT > 0 && wave * RPI < RBT;
-  const bool a_tail = RAT > 0 && wave * RPI < RAT;   // this wave issues the A tail slot (piece RAF)
 
   // ---- XCD-aware tile renumbering (bijective for any grid size) ----------------------------
   const int tiles_n = (p.N + BN - 1) / BN;
@@ -258,13 +205,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   const int KT = T1 + p.C2 / BK;        // K-tiles of the A side (the W side has WPA per A tile)
   // this block's K-tile range (split-K: blockIdx.y)
   const int split = blockIdx.y;
-#ifdef VGEN_BUFDMA
-  const int kt_begin = to_sgpr((int)(((int64_t)KT * split) / splitk));
-  const int kt_end = to_sgpr((int)(((int64_t)KT * (split + 1)) / splitk));
-#else
   const int kt_begin = (int)(((int64_t)KT * split) / splitk);
   const int kt_end = (int)(((int64_t)KT * (split + 1)) / splitk);
-#endif
   // `ablate` (tuning switch VGEN_TAPGEMM_ABLATE, 0 in production): bit 0 skips the K loop, bit 1 the epilogue's
   // stores — the phase decomposition of a launch (profiles/r02_tapgemm_ablation.json); bit 2 takes the 8-byte
   // store path for 16-bit outputs (A/B of the paired 16-byte stores); bit 3 see lm0 above
@@ -278,120 +220,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   // (v3a recomputed rows, bounds and 64-bit products every K-tile: ~700 ALU instructions per wave
   // per K-tile against 32 MFMAs — the loop was issue-bound, not memory- or MFMA-bound.)
   constexpr int NP = LPT + (RBT > 0 ? 1 : 0);
-#ifdef VGEN_BUFDMA
-  unsigned vo[NP];                               // per-lane byte offset of piece j inside its operand's window
-  int so_a = 0, so_w;                            // scalar byte offsets of the NEXT K-tile to issue
-  const int src_cb = (ld_c ^ swz_key<CPR>(ld_r)) * 16;   // byte offset of this lane's source chunk
-  const int wave_row0 = wave * RPI;              // first tile row written by this wave's DMA (+RPP*i)
-  int kt_next = kt_begin;                        // K-tile the offsets currently describe
-  int left;                                      // K-tiles until the A offsets must be regathered
-  const unsigned lda_b = (unsigned)p.lda * 2u, lda2_b = (unsigned)p.lda2 * 2u;     // row strides in bytes (< 2^31)
-  // first source row any live lane of this tile can touch (uniform): window base of the A resource
-  unsigned base_row;
-  if (p.mode == VGEN_TAP_CONV3X3) {
-    const unsigned hw = p.Ho * p.Wo;
-    const unsigned img0 = (unsigned)lm0 / hw;
-    const unsigned oy0 = ((unsigned)lm0 - img0 * hw) / (unsigned)p.Wo;
-    const int y2 = ((int)oy0 * p.stride - p.pad_t + p.crop_t) >> p.ups;
-    base_row = img0 * p.Hi * p.Wi + (unsigned)(y2 > 0 ? y2 : 0) * p.Wi;
-  } else if (p.mode == VGEN_TAP_TEMPORAL3) {
-    base_row = (unsigned)lm0 >= (unsigned)p.S ? (unsigned)lm0 - (unsigned)p.S : 0u;
-  } else {
-    base_row = (unsigned)lm0;
-  }
-  // (uniform values that went through the VALU — the integer divisions — must be pinned to SGPRs: a resource or scalar
-  // offset that instruction selection finds in a VGPR gets a waterfall loop around every DMA instruction)
-  base_row = (unsigned)to_sgpr((int)base_row);
-#ifdef VGEN_BUFCHECK
-  const char* abase_dbg = (const char*)A + (uint64_t)base_row * lda_b;
-  int wt_dbg = kt_begin * WPA;
-#endif
-  __amdgpu_buffer_rsrc_t rsrc_a = make_rsrc((const char*)A + (uint64_t)base_row * lda_b);
-  const __amdgpu_buffer_rsrc_t rsrc_a2 = make_rsrc((const char*)A2 + (uint64_t)(unsigned)lm0 * lda2_b);   // K segment 2
-  // offset of a live row / the out-of-range offset of a row that reads zeros.  The empty asm makes the offset an
-  // unconditional value: left alone, hipcc sinks the multiply into an exec-masked region, and every SCALAR assigned
-  // near it (so_a, left, the resource) then sits behind a divergent join — in a VGPR, with a waterfall loop around
-  // every DMA instruction that takes it as an SGPR operand
-  auto pick = [&](bool ok, unsigned off) __attribute__((always_inline)) -> unsigned {
-    asm volatile("" : "+v"(off));
-    return ok ? off : BUF_OOB;
-  };
-  auto gather_a = [&](int kt) __attribute__((always_inline)) {   // (re)compute vo[0..RA) / so_a for K-tile kt
-    // the scalars first, in straight-line code (selects, no phi behind the per-lane work below)
-    const bool seg1 = kt < T1;
-    const int tap = to_sgpr(seg1 ? kt / cpt1 : 0);
-    const int cch = kt - tap * cpt1;
-    left = to_sgpr(seg1 ? cpt1 - cch : KT - kt + 1);
-    so_a = to_sgpr(seg1 ? cch * BK * 2 : (kt - T1) * BK * 2);
-    if (seg1) {
-      if (p.mode == VGEN_TAP_CONV3X3) {
-        const int d0 = tap / 3, d1 = tap - 3 * d0;
-        const unsigned Hv = (unsigned)((p.Hi << p.ups) - 2 * p.crop_t), Wv = (unsigned)(p.Wi << p.ups);
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-          const int iy = rs[i].a + d0, ix = rs[i].b + d1;
-          const bool ok = ((unsigned)iy < Hv) & ((unsigned)ix < Wv);
-          const unsigned row = (unsigned)rs[i].base + (unsigned)((iy + p.crop_t) >> p.ups) * (unsigned)p.Wi + (unsigned)(ix >> p.ups);
-          vo[i] = pick(ok, (row - base_row) * lda_b + (unsigned)src_cb);
-        }
-      } else if (p.mode == VGEN_TAP_TEMPORAL3) {
-        const int dt_ = tap - 1;
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-          const bool ok = (unsigned)(rs[i].a + dt_) < (unsigned)p.F;
-          const unsigned row = (unsigned)(rs[i].base + dt_ * p.S);
-          vo[i] = pick(ok, (row - base_row) * lda_b + (unsigned)src_cb);
-        }
-      } else {
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-          const bool ok = rs[i].base >= 0;
-          vo[i] = pick(ok, ((unsigned)rs[i].base - base_row) * lda_b + (unsigned)src_cb);
-        }
-      }
-    } else {
-      rsrc_a = rsrc_a2;
-#ifdef VGEN_BUFCHECK
-      abase_dbg = (const char*)A2 + (uint64_t)(unsigned)lm0 * lda2_b;
-#endif
-#pragma unroll
-      for (int i = 0; i < RA; ++i) {
-        const bool ok = (mvalid >> i) & 1u;
-        vo[i] = pick(ok, (unsigned)(ld_r + RPP * i) * lda2_b + (unsigned)src_cb);
-      }
-    }
-  };
-  gather_a(kt_begin);
-  const unsigned ldw_b = (unsigned)ldw * 2u;
-  const __amdgpu_buffer_rsrc_t rsrc_w = make_rsrc((const char*)W + (uint64_t)(unsigned)ln0 * ldw_b);
-#ifdef VGEN_BUFCHECK
-  const char* const wbase_dbg = (const char*)W + (uint64_t)(unsigned)ln0 * ldw_b;
-#endif
-  so_w = kt_begin * WPA * BK * 2;
-#pragma unroll
-  for (int i = 0; i < NP - RA; ++i) {
-    const int n = ln0 + ld_r + RPP * i;
-    vo[RA + i] = pick(n < p.N, (unsigned)(ld_r + RPP * i) * ldw_b + (unsigned)src_cb);
-  }
-  auto advance_a = [&]() __attribute__((always_inline)) {   // A offset -> next A K-tile
-    ++kt_next;
-    if (--left == 0) {
-      if (kt_next < KT) gather_a(kt_next);
-    } else {
-      so_a += ROW_BYTES;
-    }
-  };
-  auto advance_w = [&]() __attribute__((always_inline)) {   // W offset -> next W K-tile
-    so_w += ROW_BYTES;
-#ifdef VGEN_BUFCHECK
-    ++wt_dbg;
-#endif
-  };
-  auto advance = [&]() __attribute__((always_inline)) {
-    advance_a();
-    advance_w();
-  };
-#else
   const char* pc[NP];
   const char* const zline = (const char*)g_zeros;
   const int src_cb = (ld_c ^ swz_key<CPR>(ld_r)) * 16;   // byte offset of this lane's source chunk
@@ -476,83 +304,18 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
     advance_a();
     advance_w();
   };
-#endif
   // LDS destination (wave-uniform) of piece j in `stage`
   auto piece_dst = [&](int stage, int j) __attribute__((always_inline)) -> unsigned char* {
     unsigned char* const base = smem + stage * STAGE_BYTES + wave_row0 * ROW_BYTES;
     return j < RA ? base + j * RPP * ROW_BYTES : base + (BM + (j - RA) * RPP) * ROW_BYTES;
   };
   auto dma = [&](int j, int stage) __attribute__((always_inline)) {   // piece j of the next K-tile -> `stage`
-#ifdef VGEN_BUFCHECK
-    {
-      const char* const ZM = (const char*)1;                    // "this lane reads zeros"
-      const char* exp_;
-      const char* got_;
-      unsigned long long so_ = 0, base_ = 0;
-      if (j < RA) {
-        const int kt = kt_next;
-        if (kt < T1) {
-          const int tap = kt / cpt1, cch = kt - tap * cpt1;
-          bool ok;
-          int64_t row;
-          if (p.mode == VGEN_TAP_CONV3X3) {
-            const int d0 = tap / 3, d1 = tap - 3 * d0;
-            const int Hv = (p.Hi << p.ups) - 2 * p.crop_t, Wv = p.Wi << p.ups;
-            const int iy = rs[j < RA ? j : 0].a + d0, ix = rs[j < RA ? j : 0].b + d1;
-            ok = (iy >= 0) & (iy < Hv) & (ix >= 0) & (ix < Wv);
-            row = (int64_t)rs[j < RA ? j : 0].base + (int64_t)((iy + p.crop_t) >> p.ups) * p.Wi + (ix >> p.ups);
-          } else if (p.mode == VGEN_TAP_TEMPORAL3) {
-            const int f2 = rs[j < RA ? j : 0].a + tap - 1;
-            ok = (f2 >= 0) & (f2 < p.F);
-            row = (int64_t)rs[j < RA ? j : 0].base + (int64_t)(tap - 1) * p.S;
-          } else {
-            ok = rs[j < RA ? j : 0].base >= 0;
-            row = rs[j < RA ? j : 0].base;
-          }
-          exp_ = ok ? (const char*)(A + row * p.lda + cch * BK) + src_cb : ZM;
-        } else {
-          const bool ok = (mvalid >> (j < RA ? j : 0)) & 1u;
-          exp_ = ok ? (const char*)(A2 + (int64_t)((unsigned)lm0 + ld_r + RPP * j) * p.lda2 + (kt - T1) * BK) + src_cb : ZM;
-        }
-        got_ = vo[j] == BUF_OOB ? ZM : abase_dbg + so_a + vo[j];
-        so_ = (unsigned)so_a;
-        base_ = (unsigned long long)abase_dbg;
-      } else {
-        const int n = ln0 + ld_r + RPP * (j - RA);
-        exp_ = n < p.N ? (const char*)(W + (int64_t)n * ldw) + (int64_t)wt_dbg * ROW_BYTES + src_cb : ZM;
-        got_ = vo[j] == BUF_OOB ? ZM : wbase_dbg + so_w + vo[j];
-        so_ = (unsigned)so_w;
-        base_ = (unsigned long long)wbase_dbg;
-      }
-      if (exp_ != got_) {
-        atomicAdd(&g_dbg[15], 1ull);
-        if (atomicCAS(&g_dbg[0], 0ull, 1ull) == 0ull) {
-          g_dbg[1] = (unsigned long long)j;
-          g_dbg[2] = (unsigned long long)(j < RA ? kt_next : wt_dbg);
-          g_dbg[3] = threadIdx.x;
-          g_dbg[4] = blockIdx.x;
-          g_dbg[5] = (unsigned long long)exp_;
-          g_dbg[6] = (unsigned long long)got_;
-          g_dbg[7] = vo[j];
-          g_dbg[8] = so_;
-          g_dbg[9] = base_;
-          g_dbg[10] = (unsigned long long)p.mode;
-          g_dbg[11] = (unsigned long long)(j < RA ? (const char*)A : (const char*)W);
-        }
-      }
-    }
-#endif
-#ifdef VGEN_BUFDMA
-    if (j < RA) blds16(rsrc_a, vo[j], so_a, piece_dst(stage, j));
-    else blds16(rsrc_w, vo[j], so_w, piece_dst(stage, j));
-#else
     glds16(pc[j], piece_dst(stage, j));
-#endif
   };
   auto load_tile = [&](int stage) __attribute__((always_inline)) {   // all pieces of the next K-tile back to back
 #pragma unroll
     for (int j = 0; j < LPT; ++j)
-      if (!(RAT > 0 && j == RAF) || a_tail) dma(j, stage);
+      dma(j, stage);
     if (RBT > 0 && w_tail) dma(NP - 1, stage);
     advance();
   };
@@ -644,7 +407,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
         if (i % GRP == 0) {
           if (prefetch) {
             if (piece < LPT) {
-              if (!(RAT > 0 && piece == RAF) || a_tail) dma(piece, stage_pf);
+              dma(piece, stage_pf);
             } else if (RBT > 0 && piece == NP - 1 && w_tail) {
               dma(NP - 1, stage_pf);
             }
@@ -698,7 +461,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
       if (prefetch && (r % EVERY) == EVERY - 1 && piece < NP) {
         __builtin_amdgcn_sched_barrier(0);
         if (piece < LPT) {
-          if (!(RAT > 0 && piece == RAF) || a_tail) dma(piece, stage_pf);
+          dma(piece, stage_pf);
         } else if (RBT > 0 && w_tail) {
           dma(NP - 1, stage_pf);
         }
@@ -711,7 +474,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
       for (int j = 0; j < NP; ++j)
         if (j >= piece) {
           if (j < LPT) {
-            if (!(RAT > 0 && j == RAF) || a_tail) dma(j, stage_pf);
+            dma(j, stage_pf);
           } else if (RBT > 0 && w_tail) {
             dma(NP - 1, stage_pf);
           }
@@ -749,20 +512,13 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
     st_l = st_l == STAGES - 1 ? 0 : st_l + 1;
   };
   auto wait_next = [&]() __attribute__((always_inline)) {   // all but the newest tile's pieces have landed
-    constexpr int BASE = LPT - (RAT > 0 ? 1 : 0);           // pieces every wave issues per tile; + the tails it is in
-    const int extra = (a_tail ? 1 : 0) + (w_tail ? 1 : 0);
-    if (RAT > 0 && extra == 2) wait_vmcnt<BASE + 2>();
-    else if (extra == 1) wait_vmcnt<BASE + 1>();
-    else wait_vmcnt<BASE>();
+    if (w_tail) wait_vmcnt<LPT + 1>();                      // pieces this wave issues per tile (+ the W tail it is in)
+    else wait_vmcnt<LPT>();
   };
   auto wait_next_w = [&]() __attribute__((always_inline)) {   // ... when the newest tile is a dual-W odd one (W pieces only)
     if (w_tail) wait_vmcnt<LPT - RA + 1>();
     else wait_vmcnt<LPT - RA>();
   };
-#ifdef VGEN_STAMP
-  unsigned long long st_acc[STAMP_SLOTS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-  unsigned long long st_prev = 0, st_t0 = 0;
-#endif
   if constexpr (PP && DW) {
     // K-steps come in (even, odd) pairs: nk is even.  Tile t+2 has the parity of tile t, so an even step issues (and
     // leaves in flight) a full tile, an odd step the W pieces only; each waits for the tile of the OTHER parity.
@@ -772,36 +528,26 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
       __builtin_amdgcn_s_barrier();
       if (follower) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
-#ifdef VGEN_STAMP
-      st_prev = st_t0 = __builtin_amdgcn_s_memtime();
-#endif
       auto dw_step = [&](auto prefetch_tag, auto odd_tag) __attribute__((always_inline)) {
         constexpr bool pf = decltype(prefetch_tag)::value;
         constexpr bool odd = decltype(odd_tag)::value;
-        constexpr int SB = odd ? 5 : 0;
-        (void)SB;
         read_phase(st_c, prefetch_tag, st_l, odd_tag);
-        VGEN_STAMP_AT(SB + 0);
         if constexpr (pf) {
           if constexpr (odd) wait_next_w();             // tile it+1 (even: full) landed, it+2 (odd: W only) may fly
           else wait_next();                             // tile it+1 (odd) landed, it+2 (even: full) may fly
         } else {
           wait_vmcnt<0>();
         }
-        VGEN_STAMP_AT(SB + 1);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        VGEN_STAMP_AT(SB + 2);
         __builtin_amdgcn_sched_barrier(0);
         mfma_phase();
         __builtin_amdgcn_sched_barrier(0);
-        VGEN_STAMP_AT(SB + 3);
         if constexpr (pf) {
           if constexpr (!odd) advance_a();
           advance_w();
         }
         __builtin_amdgcn_s_barrier();
-        VGEN_STAMP_AT(SB + 4);
         asm volatile("" ::: "memory");
         rotate();
       };
@@ -820,29 +566,21 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
     __builtin_amdgcn_s_barrier();                       // tile 0 published
     if (follower) __builtin_amdgcn_s_barrier();         // run one phase behind
     asm volatile("" ::: "memory");
-#ifdef VGEN_STAMP
-    st_prev = st_t0 = __builtin_amdgcn_s_memtime();
-#endif
     auto pp_step = [&](auto prefetch_tag, bool more) __attribute__((always_inline)) {
       read_phase(st_c, prefetch_tag, st_l, std::false_type{});
-      VGEN_STAMP_AT(0);
       // tile it+1 (issued one iteration ago) must have landed before the NEXT read phase of anyone
       if (more) wait_next();
       else wait_vmcnt<0>();
-      VGEN_STAMP_AT(1);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-      VGEN_STAMP_AT(2);
       __builtin_amdgcn_sched_barrier(0);
       mfma_phase();
       __builtin_amdgcn_sched_barrier(0);
-      VGEN_STAMP_AT(3);
       // the pointer step of this wave's next DMA issue runs here, behind the queued MFMAs: a K-step lasts two READ
       // phases (the matrix phase of one wave group hides under the read phase of the other), so VALU work moved
       // out of the read phase shortens the step twice over
       if (decltype(prefetch_tag)::value) advance();
       __builtin_amdgcn_s_barrier();
-      VGEN_STAMP_AT(4);
       asm volatile("" ::: "memory");
       rotate();
     };
@@ -872,16 +610,6 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
     }
   }
 
-#ifdef VGEN_STAMP
-  if constexpr (PP) {
-    st_acc[10] = (unsigned long long)nk;
-    st_acc[11] = st_prev - st_t0;
-    if ((int)blockIdx.x < STAMP_BLOCKS && (threadIdx.x & 63) == 0) {
-#pragma unroll
-      for (int k = 0; k < STAMP_SLOTS; ++k) g_stamp[((int)blockIdx.x * 8 + wave) * STAMP_SLOTS + k] = st_acc[k];
-    }
-  }
-#endif
   if (splitk > 1) {   // raw fp32 partial tile -> workspace [split][M][N]; epilogue in the reducer
     float* const wsp = ws + (int64_t)split * p.M * p.N;
 #pragma unroll
@@ -1166,13 +894,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vgen_tapgemm_a
 // small cost model (microseconds; constants fitted to profiles/r01_*_tapgemm_shapes.json):
 //   cost = rounds(tiles * s / slots) * (ceil(KT / s) * t_ktile + t_tile) + [s > 1] * reduce(s)
 // with KT in 64-element K-steps, slots = 256 ("pp", one block per CU) or 512 ("dual").
-enum Shape { SHAPE_PP = 0, SHAPE_DUAL = 1, SHAPE_PP128 = 2, SHAPE_DUAL224 = 3, SHAPE_PP224 = 4 };
-// SHAPE_DUAL224 (experiment, -DVGEN_BM224 only): the dual shape on 224-row tiles (2 x 2 waves of 112 x BN/2, the A side
-// staged in 3.5 DMA passes).  Every row count of the t2v UNet is 7 * 2^k, so 256-row tiles leave the last round over the
-// CUs at most 87.5 % full; 224 = 7 * 32 rows give 256 / 64 / 16 / 4 m-tiles at the four levels.
-// SHAPE_PP224 (same switch): the ping-pong schedule on 224 x 320 tiles with 32-element K-tiles, 2 x 4 waves of 112 x 80
-// (35 MFMAs per wave and K-tile against 12 fragment reads; 25 % less operand traffic per FLOP than 256 x 160), for the
-// launches without column statistics whose N is a multiple of 320.  bn = 320 in its plans.
+enum Shape { SHAPE_PP = 0, SHAPE_DUAL = 1, SHAPE_PP128 = 2 };
+// r04: 224-row tiles (every row count of the t2v UNet is 7 * 2^k, so 256-row tiles fill the last round over the CUs at
+// most 87.5 %) were built as a dual 224 x BN shape and a 224 x 320 ping-pong shape, passed every parity case they are legal
+// for, and measured +0.5 % (mixed) / +1.4 % (single-pass) SLOWER on the whole step in a same-box A/B
+// (profiles/r04a_ab_libs.jsonl); so was the buffer-resource LDS-DMA (+0.1 / +0.6 %).  Both were removed again (history:
+// commits 34443ca, 6b9d39a).
 
 struct Plan {
   int shape;
@@ -1229,11 +956,6 @@ Plan make_plan(const vgen_tapgemm_args& a) {
     // the cost model itself only proposes it when neither 128 nor 160 divides N
     bool ok = bn == 64 && a.N % 64 == 0 && (!geglu || a.N % 64 == 0);
     for (int c = 0; c < nc; ++c) ok |= cands[c] == bn;
-#ifdef VGEN_BM224
-    if (shape == SHAPE_DUAL224) return ok && sk == 1 && !a.colstats && !a.dualw;
-    if (shape == SHAPE_PP224)
-      return bn == 320 && a.N % 320 == 0 && !geglu && !a.colstats && !a.dualw && sk >= 1 && sk <= (smax < 1 ? 1 : smax);
-#endif
     return ok && shape >= SHAPE_PP && shape <= SHAPE_PP128 && sk >= 1 && sk <= (smax < 1 ? 1 : smax) &&
            !(a.colstats && shape == SHAPE_PP128) && !(a.dualw && shape == SHAPE_DUAL);
   };
@@ -1300,35 +1022,6 @@ Plan make_plan(const vgen_tapgemm_args& a) {
       }
     }
   }
-#ifdef VGEN_BM224
-  // the same dual-shape cost with 224-row tiles: 7/8 of the K-loop work per block, ceil(M / 224) m-tiles
-  if (best.shape == SHAPE_DUAL && best.splitk == 1 && !a.colstats && !a.dualw && force_shape < 0) {
-    const int bi = best.bn == 128 ? 0 : (best.bn == 160 ? 1 : 2);
-    static const double t_d1[3] = {1.10, 1.30, 0.75};
-    static const double t_d2[3] = {2.20, 2.50, 1.40};
-    auto dual_cost = [&](int bm) {
-      const int64_t blocks = ((a.M + bm - 1) / bm) * ((a.N + best.bn - 1) / best.bn);
-      const double f = bm / 256.0;
-      return blocks <= 256 ? KT * t_d1[bi] * f + 10.0 + epi_us
-                           : (double)((blocks + 511) / 512) * (KT * t_d2[bi] * f + 9.0) + 0.5 * epi_us + 1.0;
-    };
-    if (dual_cost(224) < dual_cost(256) - 1e-9) best.shape = SHAPE_DUAL224;
-  }
-  // 224 x 320 ping-pong tiles: ~1.9 us per 64 elements of K (a guess from the 256 x 160 figure scaled by the tile area and
-  // the better operand ratios — to be fitted like the others once it has run)
-  if (a.N % 320 == 0 && !geglu && !a.colstats && !a.dualw && force_shape < 0) {
-    const int64_t tiles = ((a.M + 223) / 224) * (a.N / 320);
-    for (int sk = 1; sk <= (smax < 1 ? 1 : smax); ++sk) {
-      const int kts = (KT + sk - 1) / sk;
-      double cost = (double)((tiles * sk + 255) / 256) * (kts * 1.9 + 8.0) + epi_us;
-      if (sk > 1) cost += 5.0 + (double)(sk + 1) * a.M * a.N * 4.0 / 3.0e6;
-      if (cost < best_cost - 1e-9 && (best.shape != SHAPE_DUAL224)) {
-        best_cost = cost;
-        best = Plan{SHAPE_PP224, 320, sk};
-      }
-    }
-  }
-#endif
   return best;
 }
 
@@ -1404,16 +1097,6 @@ int dispatch(const vgen_tapgemm_args& a, hipStream_t s) {
       default: return launch<T, 128, 64, 64, 4, 2, 3, true>(a, pl.splitk, s);
     }
   }
-#ifdef VGEN_BM224
-  if (pl.shape == SHAPE_PP224) return launch<T, 224, 320, 32, 2, 4, 3, true>(a, pl.splitk, s);
-  if (pl.shape == SHAPE_DUAL224) {
-    switch (pl.bn) {
-      case 128: return launch<T, 224, 128, 32, 2, 2, 3, false>(a, pl.splitk, s);
-      case 160: return launch<T, 224, 160, 32, 2, 2, 3, false>(a, pl.splitk, s);
-      default: return launch<T, 224, 64, 32, 2, 2, 3, false>(a, pl.splitk, s);
-    }
-  }
-#endif
   switch (pl.bn) {
     case 128: return launch<T, 256, 128, 32, 2, 2, 3, false>(a, pl.splitk, s);
     case 160: return launch<T, 256, 160, 32, 2, 2, 3, false>(a, pl.splitk, s);
@@ -1506,24 +1189,6 @@ extern "C" int vgen_tapgemm(const vgen_tapgemm_args* args, void* stream) {
   VGEN_REQUIRE(a.M + 256 < (1LL << 31), "tapgemm: M overflows int32 row index");
   VGEN_REQUIRE(a.lda >= 0 && a.lda < (1LL << 30) && a.lda2 >= 0 && a.lda2 < (1LL << 30),
                "tapgemm: lda / lda2 must be in [0, 2^30)");
-#ifdef VGEN_BUFDMA
-  {
-    // per-lane DMA offsets are 32-bit, relative to the first source row of a block's tile: the rows one 256-row tile
-    // can touch, times the row stride, must stay below 2^31
-    int64_t span = 256;
-    if (a.mode == VGEN_TAP_CONV3X3) {
-      const int64_t imgs = a.M / ((int64_t)a.Ho * a.Wo);
-      span = (256 / a.Wo + 3) * (int64_t)a.stride * a.Wi + (256 / ((int64_t)a.Ho * a.Wo) + 1) * (int64_t)a.Hi * a.Wi;
-      if (span > imgs * a.Hi * a.Wi) span = imgs * a.Hi * a.Wi;
-    } else if (a.mode == VGEN_TAP_TEMPORAL3) {
-      span = 256 + 2 * (int64_t)a.S;
-    }
-    const int64_t ldw_eff = a.ldw ? a.ldw : ((int64_t)a.taps * a.C1 + a.C2) * (a.dualw ? 2 : 1);
-    VGEN_REQUIRE(span * a.lda * 2 < (1LL << 31) - (1 << 20) && 256 * a.lda2 * 2 < (1LL << 31) - (1 << 20) &&
-                     256 * ldw_eff * 2 < (1LL << 31) - (1 << 20),
-                 "tapgemm: a tile's source window exceeds 2 GiB (rows %lld x lda %lld)", (long long)span, (long long)a.lda);
-  }
-#endif
   VGEN_REQUIRE(((int64_t)a.taps * a.C1 + a.C2) * (a.dualw ? 4 : 2) <= ZERO_BYTES - 128,
                "tapgemm: K = %lld too long (<= 131008; <= 65504 with dualw)",
                (long long)((int64_t)a.taps * a.C1 + a.C2));
@@ -1550,32 +1215,4 @@ extern "C" int vgen_tapgemm(const vgen_tapgemm_args* args, void* stream) {
   return a.dtype == VGEN_BF16 ? dispatch<BF16>(a, s) : dispatch<F16>(a, s);
 }
 
-#ifdef VGEN_STAMP
-// probe build only (not declared in include/vgen_hip.h): copy the segment counters of the last launch to a device buffer
-namespace {
-__global__ void stamp_copy_kernel(unsigned long long* dst) {
-  const int i = (int)blockIdx.x * 256 + (int)threadIdx.x;
-  if (i < STAMP_BLOCKS * 8 * STAMP_SLOTS) dst[i] = g_stamp[i];
-}
-}  // namespace
-extern "C" __attribute__((visibility("default"))) int vgen_debug_stamps(void* dev_dst, void* stream) {
-  stamp_copy_kernel<<<(STAMP_BLOCKS * 8 * STAMP_SLOTS + 255) / 256, 256, 0, (hipStream_t)stream>>>((unsigned long long*)dev_dst);
-  return (int)hipGetLastError();
-}
-#endif
 
-#ifdef VGEN_BUFCHECK
-namespace {
-__global__ void dbg_copy_kernel(unsigned long long* dst) {
-  const int i = (int)threadIdx.x;
-  if (i < 16) {
-    dst[i] = g_dbg[i];
-    g_dbg[i] = 0;
-  }
-}
-}  // namespace
-extern "C" __attribute__((visibility("default"))) int vgen_debug_dump(void* dev_dst) {
-  dbg_copy_kernel<<<1, 64, 0, 0>>>((unsigned long long*)dev_dst);
-  return (int)hipGetLastError();
-}
-#endif

@@ -211,9 +211,9 @@ class GaussianDiffusion(object):
                             cc = float(((-h - eta_h).expm1().neg() / (-h - eta_h) + 1) * (1 / r))
                         else:
                             cc = float(0.5 * (-h - eta_h).expm1().neg() * (1 / r))
-                    cn = float(sig[i + 1] * (-2 * eta_h).expm1().neg().sqrt() * s_noise)
+                    cn = (float(sig[i + 1]), float((-2 * eta_h).expm1().neg().sqrt()), float(s_noise))
                     nz = None
-                    if cn != 0.0:
+                    if cn[0] * cn[1] * cn[2] != 0.0:
                         nz = sampler(sig[i], sig[i + 1]).to(device=x.device, dtype=torch.float32).contiguous()
                     # exponential-integrator step + 2M correction + noise injection: ONE launch (vgen_dpmpp2m_sde_step)
                     x = be.dpmpp2m_sde_step(x, denoised, old_denoised if use_old else None, nz, ca, cb, cc, cn)

@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("VGEN_HIP_LIB") or os.path.join(HERE, "libvgen_hip.so"
 VGEN_BF16, VGEN_F16, VGEN_F32 = 0, 1, 2
 TAP_LINEAR, TAP_CONV3X3, TAP_TEMPORAL3 = 0, 1, 2
 EPI_NONE, EPI_GEGLU = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class VgenHipError(RuntimeError):
@@ -100,7 +100,7 @@ SYMBOLS = {
     "vgen_lincomb4": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _i64, _vp]),
     "vgen_repeat_rows": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "vgen_gather_rows_f32": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _vp, _vp]),
-    "vgen_dpmpp2m_sde_step": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _vp, _i64, _vp]),
+    "vgen_dpmpp2m_sde_step": (C.c_int, [_vp, _vp, _vp, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _vp, _i64, _vp]),
 }
 
 _lib = None

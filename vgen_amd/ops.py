@@ -532,12 +532,15 @@ class HipBackend:
         return out
 
     def dpmpp2m_sde_step(self, x, denoised, old, noise, ca, cb, cc, cn):
-        """One DPM-Solver++(2M) SDE update in one launch (vgen_dpmpp2m_sde_step)."""
+        """One DPM-Solver++(2M) SDE update in one launch (vgen_dpmpp2m_sde_step); cn = (sigma_next, sqrt(-expm1(-2 eta
+        h)), s_noise), applied to the noise one after the other like the reference's statement."""
+        cn1, cn2, cn3 = cn
         for t in (x, denoised, old, noise):
             assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
         out = torch.empty_like(x)
         rc = self.lib.vgen_dpmpp2m_sde_step(_ptr(x), _ptr(denoised), _ptr(old), _ptr(noise), float(ca), float(cb),
-                                            float(cc), float(cn), _ptr(out), x.numel(), self._stream(x))
+                                            float(cc), float(cn1), float(cn2), float(cn3), _ptr(out), x.numel(),
+                                            self._stream(x))
         _lib.check(rc, "vgen_dpmpp2m_sde_step")
         return out
 

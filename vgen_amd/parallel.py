@@ -36,15 +36,28 @@ _FORCE_COLLECTIVE = os.environ.get("VGEN_FORCE_COLLECTIVE") == "1"
 # (unet_videolcm.py:541-560).  Everything else (config objects, flags, shared tensors) is passed through.
 PER_PROMPT_KEYS = frozenset({
     "y", "fps", "image", "local_image", "depth", "sketch", "canny", "masked", "motion", "single_sketch", "histogram",
-    "video_mask", "focus_present_mask", "x_lr", "zero_y", "y_words"})
+    "video_mask", "focus_present_mask", "x_lr", "zero_y", "y_words", "t_w"})
+
+
+def register_per_prompt_keys(*names):
+    """Custom models: declare further kwargs that are batched over the prompts (sliced per rank like `y`)."""
+    global PER_PROMPT_KEYS
+    PER_PROMPT_KEYS = PER_PROMPT_KEYS | frozenset(names)
 
 
 def _slice_kwargs(kw, ps, P):
     """kwargs of the prompts `ps`.  Only the known per-prompt keys are indexed, and only when their leading dim IS
     the prompt count; a per-prompt tensor given as a broadcast [1, ...] is expanded first.  (r02 indexed every tensor
-    whose leading dim happened to equal P and left broadcast rows unsliced: ADVICE r02.)"""
+    whose leading dim happened to equal P and left broadcast rows unsliced: ADVICE r02.)  A tensor under an UNKNOWN
+    name whose leading dim equals the prompt count while only a subset of the prompts is evaluated is ambiguous (shared
+    table or per-prompt batch?): it raises instead of being paired silently with a smaller batch —
+    register_per_prompt_keys() declares it per-prompt; reshape it or pass it under a registered name otherwise."""
     out = {}
     for k, v in kw.items():
+        if k not in PER_PROMPT_KEYS and torch.is_tensor(v) and v.dim() >= 1 and P > 1 and v.shape[0] == P and len(ps) != P:
+            raise ValueError(f"kwarg {k!r}: tensor with leading dim == prompt count {P} under a name that is not in "
+                             f"PER_PROMPT_KEYS — cannot tell a per-prompt batch from a shared tensor; call "
+                             f"vgen_amd.parallel.register_per_prompt_keys({k!r}) if it is batched over the prompts")
         if k in PER_PROMPT_KEYS and torch.is_tensor(v) and v.dim() >= 1:
             if v.shape[0] == P:
                 out[k] = v[ps]
@@ -116,7 +129,9 @@ class UnitPartition:
         U = P * G
         S = self.slots(U)
         if self.world == 1 and not _FORCE_COLLECTIVE:
-            allb = mine
+            # a COPY, not the session's static output buffer: the returned branches must survive the next eval / graph
+            # replay (multistep samplers keep a model output across steps: old_denoised of DPM-Solver++) — ADVICE r03
+            allb = mine.clone()
         else:
             if mine.shape[0] == S and mine.is_contiguous():
                 buf = mine
