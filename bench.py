@@ -20,10 +20,14 @@ session (vgen_amd/session.py) replays one hipGraph per step; the untimed setup d
 warm-up + capture), like weight loading.
 
 HEADLINE MODE = a mode that meets the north-star's tolerance: fp16 operands, precision="mixed" — packed weights as
-W_hi + W_lo pairs (one dual-W tap-GEMM launch per layer) in the blocks of the two finest resolution levels, where 95 % of
-the output's sensitivity to weight rounding sits: UNet output <= 1e-3 rel-L2 of the reference's fp32
-forward.  `parity.unet_rel_l2` is COMPUTED IN THIS RUN: the timed model evaluates the golden fixture's input and is
-compared with the reference's recorded fp32 output.  `variants` carries the same two measurements (timed steps +
+W_hi + W_lo pairs (one dual-W tap-GEMM launch per layer) in the blocks of the FULL-RESOLUTION level (encoder and decoder
+level 0, + the context K/V projection and the head conv), where 82 % of the output's sensitivity to weight rounding sits
+(DESIGN §4.1): UNet output <= 1e-3 rel-L2 of the reference's fp32 forward — measured on seeded synthetic weights (no
+checkpoints offline): three full-size t2v fixtures (two weight recipes, three timesteps) and the full-width I2VGen /
+VideoLCM / TFT2V / SR600 fixtures; on the 3-level dim-64 test model the same rule lands at 1.1e-3.
+`parity.unet_rel_l2` is COMPUTED IN THIS RUN (max over the three t2v fixtures): the timed model evaluates the golden
+fixtures' inputs and is compared with the reference's recorded fp32 outputs; a value outside the tolerance sets
+`parity_exceeds_tolerance` on the line and warns on stderr.  `variants` carries the same two measurements (timed steps +
 parity, in this run, same process) for fp16/high (two-term weights everywhere: the largest margin), fp16/fast (one
 16-bit operand pair per GEMM: the reference's own autocast arithmetic) and bf16/fast (BASELINE.json's literal "bf16") —
 the last two faster and outside 1e-3.
@@ -84,6 +88,11 @@ PEAK_TFLOPS = 2500.0        # dense bf16/fp16 MFMA, /opt/skills/guides/MI355X_MI
 PEAK_HBM_GBS = 8000.0
 TOLERANCE = 1e-3            # north_star: UNet output within 1e-3 rel-L2 of the reference
 GOLDEN_T2V = os.path.join(ROOT, "tests", "golden", "unet_t2v_full.pt")
+# r04: two more full-size fixtures of the reference's fp32 forward (oracle/make_golden.py --only t2v_extra) — the headline
+# weights at a mid-trajectory t = 501 on another input, and a second weight seed with heavy-tailed (Student-t, nu = 4)
+# matrices at t = 741.  parity.unet_rel_l2 is the MAX over all three.
+GOLDEN_T2V_C = os.path.join(ROOT, "tests", "golden", "unet_t2v_full_c.pt")
+GOLDEN_T2V_B = os.path.join(ROOT, "tests", "golden", "unet_t2v_full_b.pt")
 
 # name -> (model class path, ctor kwargs, latent [C,F,H,W], units per step G, UNet forward TFLOP,
 #          extra conditioning builder, description)
@@ -108,8 +117,16 @@ CONFIGS = {
                      desc="tft2v 32x448x256 latent [1,4,32,32,56], DDIM CFG step (2 UNetSD_TFT2V fwd + update), text+image"),
     "videolcm": dict(cls="unet_videolcm.UNetSD_VideoLCM", cfg=dict(UNET_T2V), comps=["text"],
                      latent=(4, 16, 32, 56), G=1, tflop=8.665,
-                     desc="videolcm 16x448x256 latent [1,4,16,32,56], one UNetSD_VideoLCM fwd + fused update per step "
-                          "(no CFG, as the 4-step LCM loop)"),
+                     desc="videolcm 16x448x256: whole videos as the engine makes them (inference_videolcm_entrance.py:"
+                          "171-258) — LCMScheduler.sample_loop, 4 steps of one UNetSD_VideoLCM fwd + LCM update (no CFG), "
+                          "a NEW prompt per video, then the 16-frame AutoencoderKL decode to uint8 (decoder_bs 2)"),
+    # BASELINE config 5: both stages back to back for ONE video (bench.py run_two_stage)
+    "tft2v_sr600": dict(cls="unet_videolcm.UNetSD_TFT2V", cfg=dict(UNET_T2V, num_tokens=4), comps=["text", "image"],
+                        latent=(4, 32, 64, 112), G=2, tflop=77.94,
+                        desc="tft2v 32x896x512 + sr600 32x1280x720, the full 2-stage pipeline for one video "
+                             "(inference_tft2v_sr600_entrance.py:274-321): 50 DDIM CFG steps at [1,4,32,64,112] + 32-frame "
+                             "decode; bilinear resize to 720p, 32-frame encode, 30 DDIM-inversion forwards, 30 CFG "
+                             "DPM-Solver++(2M) SDE steps at [1,4,32,90,160], 32-frame 720p decode"),
 }
 
 
@@ -238,16 +255,166 @@ class StepTimer:
         return dt_s, xt
 
 
+def _emit(res, world):
+    import torch.distributed as dist
+    print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_videolcm(args, dev, model, world, rank):
+    """BASELINE config 4 as stated: whole videos through the 4-step `LCMScheduler.sample_loop` + the 16-frame decode
+    ("decode-bound, exercises VAE kernels").  Every video is a NEW prompt (fresh context tensor, as a new caption through
+    the text tower would be): the scheduler's sampling session is re-bound to it (vgen_amd/session.py) — one K/V GEMM, no
+    re-capture.  --steps K = denoise steps timed (rounded up to whole videos of 4); value = denoise steps / s of the
+    whole-video wall time (decode included), `video` carries the split."""
+    from vgen_amd.lcm import LCMScheduler
+    from vgen_amd.vae import AutoencoderKL
+    C, F, H, W = CONFIGS["videolcm"]["latent"]
+    sched = LCMScheduler(prediction_type="v_prediction", beta_schedule="scaled_linear", clip_sample=False,
+                         timestep_spacing="linspace", rescale_betas_zero_snr=True)
+    sched.set_timesteps(4, device=dev)
+    with torch.device(dev):
+        vae = AutoencoderKL(ddconfig=VAE_SD, embed_dim=4, compute_dtype=args.dtype,
+                            precision="fast" if args.precision == "fast" else "high")
+    vae.eval()
+    randomize_(vae, 1)
+    g = torch.Generator(device=dev).manual_seed(8888 + rank)
+
+    def one_video():
+        y = torch.randn(1, 77, 1024, generator=g, device=dev)               # a new prompt
+        noise = torch.randn(1, C, F, H, W, generator=g, device=dev)
+        t0 = time.perf_counter()
+        lat = sched.sample_loop(noise, model, [dict(y=y)], guidance_scale=None, generator=g)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        vid = vae.decode_video(lat * 0.2, scale_factor=0.18215, decoder_bs=2)
+        torch.cuda.synchronize()
+        return t1 - t0, time.perf_counter() - t1, lat, vid
+
+    nvid = max(1, (args.steps + 3) // 4)
+    for _ in range(2 + max(0, (args.warmup + 3) // 4)):                     # session build + capture, re-bind, warm-up
+        one_video()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loop_s = dec_s = 0.0
+    for _ in range(nvid):
+        a, b, lat, vid = one_video()
+        loop_s, dec_s = loop_s + a, dec_s + b
+    torch.cuda.synchronize()
+    dt_s = time.perf_counter() - t0
+    steps = 4 * nvid
+    return {
+        "metric": "denoise_steps_per_sec", "value": round(steps / dt_s, 4), "unit": "steps/s", "n_gpus": world,
+        "steps": steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt_s / steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": CONFIGS["videolcm"]["desc"], "name": "videolcm", "precision": args.precision,
+                   "api": "LCMScheduler.sample_loop (4 steps) + AutoencoderKL.decode_video per video",
+                   "parallelism": "single GPU", "weights": "seeded synthetic (device-side random init)"},
+        "finite": bool(torch.isfinite(lat).all()), "video_shape": list(vid.shape),
+        "video": {"videos": nvid, "seconds_per_video": round(dt_s / nvid, 4), "videos_per_sec": round(nvid / dt_s, 3),
+                  "frames_per_sec": round(F * nvid / dt_s, 2), "sample_loop_s_per_video": round(loop_s / nvid, 4),
+                  "decode_s_per_video": round(dec_s / nvid, 4), "decode_share": round(dec_s / max(loop_s + dec_s, 1e-9), 3),
+                  "session_rebinds": sched.sessions.rebinds},
+        "model_tflops_per_s": round(CONFIGS["videolcm"]["tflop"] * steps / dt_s, 2),
+    }
+
+
+def run_two_stage(args, dev, world, rank):
+    """BASELINE config 5, one video end to end on one GPU: stage 1 = UNetSD_TFT2V, 50 DDIM CFG steps + decode; the decoded
+    frames stand in for the .mp4 the reference writes and re-reads (video writer / cv2 reader: out of scope) and go through
+    the engine's own glue (bilinear resize to 720 x 1280, inference_tft2v_sr600_entrance.py:118) into stage 2 = 32-frame
+    encode, DDIM inversion (30 forwards, reverse_steps 700), `sample(solver='dpmpp_2m_sde', steps=30)` CFG 9 / rescale 0.3,
+    32-frame 720p decode (decoder_bs 4)."""
+    import torch.nn.functional as Fn
+    from vgen_amd.diffusion import DiffusionDDIM
+    from vgen_amd.diffusion_gauss import DiffusionDDIMSR
+    from vgen_amd.vae import AutoencoderKL
+    steps1 = steps2 = 2 if args.steps < 10 else None        # --steps < 10: a 2-step smoke run of every stage
+    n1, n2 = steps1 or 50, steps2 or 30
+    g = torch.Generator(device=dev).manual_seed(8888 + rank)
+    with torch.device(dev):
+        vae = AutoencoderKL(ddconfig=VAE_SD, embed_dim=4, compute_dtype=args.dtype,
+                            precision="fast" if args.precision == "fast" else "high")
+    vae.eval()
+    randomize_(vae, 1)
+    times = {}
+
+    def lap(name, t0):
+        torch.cuda.synchronize()
+        times[name] = round(time.perf_counter() - t0, 4)
+        return time.perf_counter()
+
+    # ---- stage 1 -----------------------------------------------------------------------------------------------
+    m1 = build_model("tft2v896", dev, args.dtype, args.precision)
+    C, F, H, W = CONFIGS["tft2v_sr600"]["latent"]
+    kw1 = conditioning("tft2v896", m1, 1, dev, g)
+    d1 = DiffusionDDIM(**DDIM)
+    d1.rng_parity = False
+    noise = torch.randn(1, C, F, H, W, generator=g, device=dev)
+    torch.cuda.synchronize()
+    t_all = t0 = time.perf_counter()
+    lat = d1.ddim_sample_loop(noise, m1, kw1, guide_scale=9.0, ddim_timesteps=n1, eta=0.0)
+    t0 = lap("stage1_ddim_loop_s", t0)
+    frames = vae.decode_video(lat * 0.2, scale_factor=0.18215, decoder_bs=2, to_uint8=False)       # [1, 3, 32, 512, 896] fp32
+    t0 = lap("stage1_decode_s", t0)
+    fin1 = bool(torch.isfinite(lat).all())
+    del m1, d1
+    gc.collect()
+    torch.cuda.empty_cache()
+    # ---- stage 2 -----------------------------------------------------------------------------------------------
+    t_build = time.perf_counter()
+    m2 = build_model("sr600", dev, args.dtype, args.precision)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t_build                 # weight synthesis, not pipeline time: subtracted below
+    t0 = time.perf_counter()
+    vid = frames[0].permute(1, 0, 2, 3).clamp(-1, 1)                                   # [32, 3, 512, 896]
+    vid = Fn.interpolate(vid, size=(720, 1280), mode="bilinear")                       # the engine's glue (:118)
+    zs = [vae.encode_firsr_stage(vid[i:i + 2], 0.18215) for i in range(0, vid.shape[0], 2)]
+    z0 = torch.cat(zs, 0).permute(1, 0, 2, 3).unsqueeze(0).contiguous()               # [1, 4, 32, 90, 160]
+    t0 = lap("stage2_resize_encode_s", t0)
+    srd = DiffusionDDIMSR(**SR600_DIFF)
+    y_c = torch.randn(1, 77, 1024, generator=g, device=dev)
+    y_u = torch.randn(1, 77, 1024, generator=g, device=dev)
+    noised = srd.reverse_diffusion.ddim_reverse_sample_loop(z0, m2, {"y": y_u}, guide_scale=None, ddim_timesteps=n2,
+                                                            reverse_steps=700)
+    t0 = lap("stage2_inversion_s", t0)
+    out = srd.forward_diffusion.sample(noise=noised, model=m2, model_kwargs=[{"y": y_c}, {"y": y_u}], guide_scale=9.0,
+                                       guide_rescale=0.3, solver="dpmpp_2m_sde", steps=n2, t_max=699, t_min=0,
+                                       discretization="trailing", seed=8888)
+    t0 = lap("stage2_dpm_sample_s", t0)
+    video = vae.decode_video(out * 0.2, scale_factor=0.18215, decoder_bs=4)
+    t0 = lap("stage2_decode_s", t0)
+    total = time.perf_counter() - t_all - build_s
+    return {
+        "metric": "frames_per_sec_end_to_end", "value": round(F / total, 4), "unit": "frames/s", "n_gpus": world,
+        "steps": n1 + 2 * n2, "warmup": 0, "ms_per_step": round(1e3 * total / (n1 + 2 * n2), 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": CONFIGS["tft2v_sr600"]["desc"], "name": "tft2v_sr600", "precision": args.precision,
+                   "parallelism": "single GPU", "weights": "seeded synthetic (device-side random init)",
+                   "smoke_run": steps1 is not None,
+                   "note": "one video, cold sessions (setup + graph capture inside the timed region, as a one-shot engine "
+                           "run pays them); weight synthesis of the second model excluded"},
+        "seconds_per_video": round(total, 3), "stages": times,
+        "finite": fin1 and bool(torch.isfinite(out).all()), "video_shape": list(video.shape),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="fp16", choices=["bf16", "fp16"])
-    ap.add_argument("--config", default="t2v", choices=sorted(CONFIGS))
+    ap.add_argument("--config", default="t2v", choices=sorted(CONFIGS),
+                    help="t2v (default, BASELINE config 2: the driver's line); videolcm = whole videos through the 4-step LCM loop "
+                         "+ decode (config 4); tft2v_sr600 = the two-stage pipeline for one video (config 5; --steps < 10 runs a "
+                         "2-step smoke of every stage); the others time one denoise step of that shape")
     ap.add_argument("--precision", default="mixed",
-                    help="mixed (default): packed weights as W_hi + W_lo pairs (dual-W tap-GEMM launches) in the two finest "
-                         "resolution levels — UNet output within 1e-3 rel-L2 of the reference's fp32 forward; high: two-term "
+                    help="mixed (default): packed weights as W_hi + W_lo pairs (dual-W tap-GEMM launches) in the full-resolution "
+                         "level (encoder + decoder level 0, K/V projection, head) — UNet output within 1e-3 rel-L2 of the "
+                         "reference's fp32 forward on the full-width fixtures; high: two-term "
                          "weights everywhere; fast: one 16-bit operand pair per GEMM (the reference's autocast arithmetic; "
                          "1.33e-3); mixed:e0d01t1-style strings select levels (vgen_amd/unet.py)")
     ap.add_argument("--variants", default="fp16/high,fp16/fast,bf16/fast",
@@ -261,6 +428,10 @@ def main():
     ap.add_argument("--partition", action="store_true",
                     help="use the multi-GPU code path (UnitPartition: session over the local units + eager "
                          "gather/update) even at --gpus 1")
+    ap.add_argument("--graph-collective", action="store_true",
+                    help="partitioned runs (--gpus > 1 / --partition): the whole step — local forward, RCCL all-gather, update "
+                         "from the gathered buffer — as ONE hipGraph per step (vgen_amd/parallel.py ddim_step; r04, validated on "
+                         "one device only: off by default)")
     ap.add_argument("--vae-size", default="256x448", help="HxW of the decoded frame")
     ap.add_argument("--dump-shapes", action="store_true", help="write per-shape kernel timings to gpurun_out/")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -292,6 +463,11 @@ def main():
     ops.set_backend(None)
     assert ops.backend().name == "hip"
 
+    if args.config == "tft2v_sr600":
+        res = run_two_stage(args, dev, world, rank)
+        if rank == 0:
+            _emit(res, world)
+        return
     cfg = CONFIGS[args.config]
     C, F, H, W = cfg["latent"]
     G = cfg["G"]
@@ -303,6 +479,11 @@ def main():
     model = build_model(args.config, dev, args.dtype, args.precision, state_dict=sd)
     if args.config == "t2v":
         drop_masters(model, dev)
+    if args.config == "videolcm":
+        res = run_videolcm(args, dev, model, world, rank)
+        if rank == 0:
+            _emit(res, world)
+        return
 
     diff = DiffusionDDIM(**DDIM)
     diff.rng_parity = False
@@ -312,7 +493,7 @@ def main():
     kw = conditioning(args.config, model, P, dev, g)
     guide = 9.0 if G == 2 else None
     mkw = kw if G == 2 else kw[0]
-    part = UnitPartition() if (world > 1 or args.partition) else None
+    part = UnitPartition(graph_collective=args.graph_collective or None) if (world > 1 or args.partition) else None
     diff.partition = part
 
     inversion = None
@@ -377,7 +558,8 @@ def main():
         "config": {"workload": cfg["desc"], "name": args.config,
                    "prompts_in_flight": P, "units_per_step": G * P, "api": api,
                    "parallelism": "single GPU" if world == 1 else
-                   f"unit partition over {world} ranks, 1 all-gather/step ({args.backend}{', all ranks on one device: functional test' if one_dev else ''})",
+                   f"unit partition over {world} ranks, 1 all-gather/step ({args.backend}{', all ranks on one device: functional test' if one_dev else ''})"
+                   + (", collective inside the step graph" if (part is not None and part.graph_collective) else ""),
                    "hipgraph": bool(sess is not None and sess.use_graph and sess._graphs) and
                    ("whole step" if (part is None and args.config != "sr600") else "units' forward"),
                    "precision": args.precision,
@@ -393,11 +575,30 @@ def main():
 
     # ---- parity of the model that was just timed, computed here --------------------------------------------
     if rank == 0 and gold is not None and not args.no_parity:
-        err = golden_parity(model, gold, dev)
+        fx = {"t2v_full (the timed model: Gaussian weights seed 0, t=981)": golden_parity(model, gold, dev)}
+        if os.path.exists(GOLDEN_T2V_C):
+            gc_ = torch.load(GOLDEN_T2V_C, map_location="cpu", weights_only=False)
+            assert gc_["seed"] == gold["seed"] and gc_.get("recipe", "gauss") == "gauss"
+            fx["t2v_full_c (the timed model, t=501, other input)"] = golden_parity(model, gc_, dev)
+        if os.path.exists(GOLDEN_T2V_B) and world == 1:
+            gb_ = torch.load(GOLDEN_T2V_B, map_location="cpu", weights_only=False)
+            mb = build_model("t2v", dev, args.dtype, args.precision,
+                             state_dict=seeded_state_dict(gb_["shapes"], seed=gb_["seed"], recipe=gb_["recipe"]))
+            fx["t2v_full_b (same architecture + mode, Student-t(4) weights seed 1, t=741)"] = golden_parity(mb, gb_, dev)
+            del mb
+            gc.collect()
+            torch.cuda.empty_cache()
+        err = max(fx.values())
         res["parity"] = {"unet_rel_l2": err, "tolerance": TOLERANCE, "within_tolerance": bool(err <= TOLERANCE),
                          "dtype": args.dtype, "precision": args.precision, "measured_in_this_run": True,
-                         "golden": "tests/golden/unet_t2v_full.pt: the reference's fp32 UNetSD_T2VBase forward on the "
-                                   "same seeded weights and input (oracle/make_golden.py)"}
+                         "fixtures": {k: round(v, 7) for k, v in fx.items()},
+                         "golden": "tests/golden/unet_t2v_full{,_c,_b}.pt: the reference's fp32 UNetSD_T2VBase forward on the "
+                                   "same seeded weights and inputs (oracle/make_golden.py); unet_rel_l2 = max over the fixtures"}
+        if err > TOLERANCE:
+            # a headline whose in-run parity is outside the north-star's tolerance must say so loudly
+            res["parity_exceeds_tolerance"] = True
+            print(f"bench.py: WARNING parity {err:.3e} > tolerance {TOLERANCE:.0e} in dtype={args.dtype} "
+                  f"precision={args.precision}: this line is NOT a measurement of the north-star claim", file=sys.stderr)
         ypath = os.path.join(ROOT, "tests", "golden", "autocast_yardstick.json")
         if os.path.exists(ypath):
             val = json.load(open(ypath)).get(f"unet_t2v_full/{args.dtype}")
@@ -462,8 +663,10 @@ def main():
                            # cross-attention, so this is a few % below the reference's 2 x forward count); a dual-W launch
                            # executes 2x the MFMA work for its product: executed_over_algorithmic says how much
                            "tapgemm_tflop_per_step": round(tot_fl / 1e12, 3),
-                           "algorithmic_bytes_per_launch": round(sum((r[5] or 0.0) for r in recs) / max(len(recs), 1)),
-                           "executed_over_algorithmic": round(1.0 + sum(r[3] for r in recs if str(r[4][5]).endswith("+dw")) / max(tot_fl, 1.0), 3),
+                           "algorithmic_bytes_per_launch": round(sum(r[5][0] for r in recs) / max(len(recs), 1)),
+                           # issued MFMA work / the products' own 2 M N K: the W_lo passes of the dual-W launches AND the
+                           # doubled K columns of two-term activation segments (r03 booked the latter as algorithmic)
+                           "executed_over_algorithmic": round(sum(r[5][1] for r in recs) / max(tot_fl, 1.0), 3),
                            "measured_in_this_run": True}
         # HBM-side bytes per launch cannot be read from inside the process: they come from committed rocprofv3 PMC
         # passes of this command (tools/collect_evidence.sh -> profiles/) and are labelled as such
@@ -591,7 +794,36 @@ def main():
                 torch_ref.unet_forward(sd, x, tt, yy, 320)
                 fwd_s = time.perf_counter() - t1
             kind, what = "port", "oracle/torch_ref.py (fp32 restatement of the reference forward; /root/reference is not on this box)"
+        # the VAE leg BASELINE.md §2 promised: one 256x448 frame (latent [1,4,32,56], 1.09 TFLOP) through the fp32
+        # decoder on the same host threads — the reference's AutoencoderKL when its tree is present, else the port
+        vshapes = {k: tuple(v.shape) for k, v in __import__("vgen_amd.vae", fromlist=["AutoencoderKL"]).AutoencoderKL(
+            ddconfig=VAE_SD, embed_dim=4).state_dict().items()}
+        vsd = seeded_state_dict(vshapes, seed=0)
+        zz = torch.randn(1, 4, 32, 56, generator=gen) / 0.18215 * 0.2
+        with torch.no_grad():
+            if ref_import.available():
+                rv = R["AUTO_ENCODER"].build(dict(type="AutoencoderKL", ddconfig=dict(VAE_SD, video_kernel_size=[3, 1, 1]),
+                                                  embed_dim=4)).eval()
+                rv.load_state_dict(vsd, strict=True)
+                t1 = time.perf_counter()
+                rv.decode(zz)
+                vae_s = time.perf_counter() - t1
+            else:
+                t1 = time.perf_counter()
+                torch_ref.vae_decode(vsd, zz)
+                vae_s = time.perf_counter() - t1
+        cpu_model = "unknown"
+        try:
+            for ln in open("/proc/cpuinfo"):
+                if ln.lower().startswith("model name"):
+                    cpu_model = ln.split(":", 1)[1].strip()
+                    break
+        except OSError:
+            pass
         res["cpu_baseline"] = {"value": round(1.0 / (2 * fwd_s), 5), "unit": "steps/s", "cores": cores, "kind": kind,
+                               "cpu_model": cpu_model, "host_logical_cpus": os.cpu_count(),
+                               "vae_decode_frames_per_sec": round(1.0 / vae_s, 4),
+                               "vae_sample": f"one 256x448 frame through the fp32 AutoencoderKL decoder ({kind}): {vae_s:.2f} s",
                                "sample": f"{what}: one forward of the full-size UNet on the 16-frame latent "
                                          f"[1,4,16,32,56]: {fwd_s:.1f} s; a CFG step is two forwards"}
     if rank == 0:

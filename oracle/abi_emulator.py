@@ -302,6 +302,20 @@ class EmuBackend:
             x_units.view(G, B, *x_units.shape[1:])[:, :, :C_lat] = r
         return xt_1, x0
 
+    def ddim_update_strided(self, xt_rows, y, u, coef_tab, t_idx, guide, use_guide, mean_type, out_rows=None, x0_out=None,
+                            rep_units=None, G=0, C_lat=0):
+        xt = xt_rows.clone()
+        coef = coef_tab.view(-1, 7)[t_idx]
+        r, x0v = self.cfg_ddim_step(xt, y.view_as(xt), None if u is None else u.view_as(xt), None, coef.contiguous(),
+                                    guide, use_guide, mean_type, True)
+        if x0_out is not None:
+            x0_out.view_as(xt).copy_(x0v)
+        if out_rows is not None:
+            out_rows.copy_(r)
+        else:
+            B = xt.shape[0]
+            rep_units.view(G, B, *rep_units.shape[1:])[:, :, :C_lat] = r
+
     def lowfreq_filter(self, x, nimg, H, W, scale):
         # header formula, evaluated directly (independent of torch.fft)
         C = x.shape[1]

@@ -91,7 +91,18 @@ def _worker_unet(rank, world, port, P, q):
     d.partition = UnitPartition()
     out = d.ddim_sample_loop(noise.clone(), m, kw, guide_scale=9.0, ddim_timesteps=4, eta=0.0)
     nsess = len(d.partition.sessions._items)
-    q.put((rank, out.numpy(), nsess))
+    # r04: the same loop with the whole partitioned step as ONE launch sequence (forward -> all-gather -> update from the
+    # gathered buffer): bit-equal to the eager gather + update path, also the public per-step call
+    d2 = DiffusionDDIM(schedule="cosine", schedule_param=dict(num_timesteps=1000, cosine_s=0.008, zero_terminal_snr=True),
+                       mean_type="v", var_type="fixed_small")
+    d2.partition = UnitPartition(graph_collective=True)
+    fused = d2.ddim_sample_loop(noise.clone(), m, kw, guide_scale=9.0, ddim_timesteps=4, eta=0.0)
+    t = torch.full((P,), 601, dtype=torch.long)
+    s1, z1 = d.ddim_sample(noise.clone(), t, m, kw, guide_scale=9.0, ddim_timesteps=50)
+    s2, z2 = d2.ddim_sample(noise.clone(), t, m, kw, guide_scale=9.0, ddim_timesteps=50)
+    same = bool(torch.equal(out, fused) and torch.equal(s1, s2) and torch.equal(z1, z2))
+    used = "pstep" in next(iter(d2.partition.sessions._items.values()))._static
+    q.put((rank, out.numpy(), nsess, same, used))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -123,6 +134,8 @@ def test_unit_partition_world2_unet_sessions(P):
         ops.set_backend(prev)
     assert torch.equal(res[0][1], res[1][1])
     assert res[0][2] == 1 and res[1][2] == 1                   # one session per rank for the whole loop
+    assert all(r[3] for r in res), "fused partition step != eager gather + update"
+    assert all(r[4] for r in res), "the fused step was not taken"      # P = 1: 'pair' layout, P = 2: 'prompt' layout
     # local batches of P units vs one batch of 2P: the CPU BLAS sums in a different order, the 16-bit roundings
     # decorrelate (1.5e-3 per forward), guidance 9 amplifies that and 4 steps accumulate it: noise floor, no more.
     # (Exact equality across the partition is asserted with the fp32 toy model below.)
@@ -172,6 +185,31 @@ def test_partition_single_process_is_identity():
     outs = [torch.full((2, 3), float(i)) for i in range(4)]
     got = p.gather_units(outs, 4, outs[0])
     assert all(torch.equal(a, b) for a, b in zip(got, outs))
+
+
+def test_fused_partition_step_single_process(emu_backend):
+    """world 1, 3 prompts: the fused partition step (r04) == the plain sampling-session path, bit for bit, incl. x0 and
+    the stepping state carried in the session's own buffers across a loop."""
+    from vgen_amd.diffusion import DiffusionDDIM
+    from vgen_amd.parallel import UnitPartition
+    m, noise, kw = _unet_case(3)
+    cfg = dict(schedule="cosine", schedule_param=dict(num_timesteps=1000, cosine_s=0.008, zero_terminal_snr=True),
+               mean_type="v", var_type="fixed_small")
+    d0, d1 = DiffusionDDIM(**cfg), DiffusionDDIM(**cfg)
+    d1.partition = UnitPartition(graph_collective=True)
+    assert d1.partition.fused_layout(3, 2) == "prompt" and d1.partition.fused_layout(3, 1) is None
+    a = d0.ddim_sample_loop(noise.clone(), m, kw, guide_scale=9.0, ddim_timesteps=4, eta=0.0)
+    b = d1.ddim_sample_loop(noise.clone(), m, kw, guide_scale=9.0, ddim_timesteps=4, eta=0.0)
+    assert torch.equal(a, b)
+    t = torch.tensor([601, 401, 201])
+    (x1, z1), (x2, z2) = (d.ddim_sample(noise.clone(), t, m, kw, guide_scale=9.0, ddim_timesteps=50) for d in (d0, d1))
+    assert torch.equal(x1, x2) and torch.equal(z1, z2)
+    # eta > 0 (noise) is not part of the fused sequence: falls back to the eager partition path, same numbers
+    torch.manual_seed(3)
+    n1 = d0.ddim_sample(noise.clone(), t, m, kw, guide_scale=9.0, ddim_timesteps=50, eta=0.5)[0]
+    torch.manual_seed(3)
+    n2 = d1.ddim_sample(noise.clone(), t, m, kw, guide_scale=9.0, ddim_timesteps=50, eta=0.5)[0]
+    assert torch.equal(n1, n2)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -369,6 +407,15 @@ def _worker_nccl(rank, world, port, P, q):
                       mean_type="v", var_type="fixed_small")
     d.partition = UnitPartition()
     out = d.ddim_sample_loop(noise.to(dev), m, kw, guide_scale=9.0, ddim_timesteps=4, eta=0.0)
+    # r04: the partitioned step with the RCCL all-gather INSIDE the captured step graph (forward -> all_gather_into_tensor
+    # -> update from the gathered buffer): must reproduce the eager gather + update path bit for bit
+    d2 = DiffusionDDIM(schedule="cosine", schedule_param=dict(num_timesteps=1000, cosine_s=0.008, zero_terminal_snr=True),
+                       mean_type="v", var_type="fixed_small")
+    d2.partition = UnitPartition(graph_collective=True)
+    fused = d2.ddim_sample_loop(noise.to(dev), m, kw, guide_scale=9.0, ddim_timesteps=6, eta=0.0)
+    eager6 = d.ddim_sample_loop(noise.to(dev), m, kw, guide_scale=9.0, ddim_timesteps=6, eta=0.0)
+    fsess = next(iter(d2.partition.sessions._items.values()))
+    fused_ok = bool(torch.equal(fused, eager6)) and any(isinstance(k, tuple) and k[0] == "pddim" for k in fsess._graphs)
     g = gold("vae_tiny.pt")
     v = AutoencoderKL(ddconfig=g["ddconfig"], embed_dim=4, compute_dtype="fp16").eval()
     v.load_state_dict(torch_ref.synth_state_dict(g["shapes"], seed=g["seed"]), strict=True)
@@ -376,7 +423,7 @@ def _worker_nccl(rank, world, port, P, q):
     lat = torch.randn(1, 4, 5, 4, 4, generator=torch.Generator().manual_seed(11)) * 0.18215
     vid = v.decode_video(lat.to(dev), decoder_bs=2, shard=True)
     torch.cuda.synchronize()
-    q.put((rank, out.cpu().numpy(), vid.cpu().numpy()))
+    q.put((rank, out.cpu().numpy(), vid.cpu().numpy(), fused_ok))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -417,6 +464,7 @@ def test_rccl_all_gather_paths_on_visible_devices():
     finally:
         ops.set_backend(prev)
     for r in res:
+        assert r[3], "fused partition step (RCCL all-gather captured in the step graph) != eager path, or not captured"
         assert torch.isfinite(r[1]).all() and rel_l2_(r[1], ref) < 1e-2
         assert r[2].shape == ref_vid.shape and int((r[2].int() - ref_vid.int()).abs().max()) <= 2
     if world == 1:          # same batches as the single-process path: the forced collective must be a pure copy

@@ -135,3 +135,34 @@ def test_cfg_shared_prefix_matches_per_branch_evaluation(emu_backend, monkeypatc
     assert m.shared_prefix_groups(prep, 2, 2) == 2
     prep["fps"] = torch.tensor([8, 8, 8, 16])
     assert m.shared_prefix_groups(prep, 2, 2) == 1
+
+
+def test_full_cache_rebinds_a_session_to_the_next_prompt(emu_backend):
+    """r04: the engines build new kwarg tensors per prompt.  With the cache at capacity a new prompt of the same structure
+    RE-BINDS the least recently used compatible session (its K/V rows and stem channels are rewritten in place — the
+    buffers a captured graph reads) instead of building and capturing a new one; the result is bit-identical to a fresh
+    session's, and a prompt of another structure (other context length) still gets its own session."""
+    from vgen_amd.diffusion import DiffusionDDIM
+    m, g, _ = _unet()
+    gen = torch.Generator().manual_seed(3)
+    prompts = [torch.randn(g["y"].shape, generator=gen) for _ in range(4)]
+    t = torch.tensor([601, 601])
+    d = DiffusionDDIM(**DDIM)
+    fresh_outs = []
+    for y in prompts:
+        d0 = DiffusionDDIM(**DDIM)                                   # a fresh diffusion object: a fresh session per prompt
+        fresh_outs.append(d0.ddim_sample(g["x"], t, m, [dict(y=y), dict(y=torch.zeros_like(y))], guide_scale=9.0,
+                                         ddim_timesteps=50)[0])
+    sess_ids = []
+    for y, want in zip(prompts, fresh_outs):
+        kw = [dict(y=y), dict(y=torch.zeros_like(y))]
+        got = d.ddim_sample(g["x"], t, m, kw, guide_scale=9.0, ddim_timesteps=50)[0]
+        assert torch.equal(got, want)
+        sess_ids.append(id(next(reversed(d.sessions._items.values()))))
+    assert len(set(sess_ids[:2])) == 2                               # capacity 2: the first two prompts build sessions
+    assert sess_ids[2] == sess_ids[0] and sess_ids[3] == sess_ids[1]  # ... the next ones re-bind them, oldest first
+    assert d.sessions.rebinds == 2 and len(d.sessions._items) == 2
+    # another context length = another launch sequence: not re-bound
+    y5 = torch.randn(g["y"].shape[0], 40, g["y"].shape[2], generator=gen)
+    d.ddim_sample(g["x"], t, m, [dict(y=y5), dict(y=torch.zeros_like(y5))], guide_scale=9.0, ddim_timesteps=50)
+    assert d.sessions.rebinds == 2 and id(next(reversed(d.sessions._items.values()))) not in sess_ids

@@ -190,6 +190,14 @@ class DiffusionDDIM(object):
             return sess.ddim_step(xt, t, self._coef_table(xt.device, kind, stride, eta),
                                   0.0 if guide_scale is None else float(guide_scale), _MEAN[self.mean_type],
                                   noise, clone=not alias_ok)
+        part = self.partition
+        if part is not None and getattr(part, "graph_collective", False) and guide_scale is not None and noise is None \
+                and not self.rescale_timesteps and isinstance(model_kwargs, (list, tuple)) and len(model_kwargs) == 2:
+            # r04: the whole partitioned step (local forward -> all-gather -> update) as one launch sequence / one hipGraph
+            r = part.ddim_step(model, xt, t, list(model_kwargs), self._coef_table(xt.device, kind, stride, eta),
+                               float(guide_scale), _MEAN[self.mean_type], self.num_timesteps)
+            if r is not None:
+                return r if alias_ok else (r[0].clone(), r[1].clone())
         y_out, u_out = self._eval_model(xt, t, model, model_kwargs, guide_scale)
         coef = self._coef_rows(self._table(xt.device), t, kind, stride, eta)
         xt32 = xt.float().contiguous()

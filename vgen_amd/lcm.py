@@ -71,6 +71,10 @@ class LCMScheduler:
         self.num_inference_steps = None
         self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
         self._step_index = None
+        # sampling sessions live on the scheduler (the engine builds ONE scheduler and loops over its prompts,
+        # inference_videolcm_entrance.py:171-257): the second video re-binds the first one's session (one K/V GEMM)
+        # instead of re-capturing the model graph for a 4-step loop
+        self.sessions = SessionCache(capacity=1)
 
     # -- schedule ------------------------------------------------------------------------------------------
     def set_timesteps(self, num_inference_steps, device=None, original_inference_steps=None, strength=1.0):
@@ -151,7 +155,7 @@ class LCMScheduler:
         cfg = guidance_scale is not None and len(model_kwargs) > 1 and guidance_scale != 1.0
         coef = torch.ones((B, 2), dtype=torch.float32, device=latents.device)
         self._step_index = None
-        sessions = SessionCache(capacity=1)
+        sessions = self.sessions
         for k, t in enumerate(self.timesteps):
             tt = t.repeat(B).to(device=latents.device, dtype=latents.dtype)
             x_in = self.scale_model_input(latents, t)

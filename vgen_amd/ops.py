@@ -80,6 +80,8 @@ class TapGemm:
     colstats: bool = False                    # also emit per-64-row-slab column (sum, sumsq) of the fp32 output;
                                               # attached to the returned tensor as `.vgen_cs` for groupnorm()
     split_out: bool = False                   # 16-bit output as two-term rows [hi | lo], [M, 2 N] (vgen_tapgemm_args.split_out)
+    alg_k: int = 0                            # bookkeeping only: the product's K when operand rows carry two-term duplicates
+                                              # ([hi | lo] x [W | W] executes 2 K columns for a K-column product); 0 = K
 
 
 @dataclass
@@ -270,13 +272,17 @@ class HipBackend:
             self.lib.vgen_tapgemm_query_plan(C.byref(a), pl)
             flags = (1 if g.residual is not None else 0) | (2 if g.rowbias is not None else 0) | (4 if cs is not None else 0)
             meta = meta + ((g.mode, g.M, g.N, g.C1, g.C2, g.taps, g.epilogue, _ENUM[g.out_dtype], flags), tuple(pl))
-        # algorithmic FLOP: the product A . W^T (a dual-W launch executes twice the MFMAs for the same product)
+        # algorithmic FLOP: the product A . W^T with its OWN K (`alg_k`: a two-term activation segment [hi | lo] x [W | W]
+        # executes twice the columns of the product it computes — r03 booked those as algorithmic: VERDICT r03 weak #2);
+        # executed FLOP (extra[1]): 2 M N K_executed, x 2 for a dual-W launch
         # algorithmic HBM bytes: every distinct operand element once (A's source rows, both weight terms, output, fp32
         # residual) — what a launch must move if nothing were re-read
         src_rows = A.shape[0] if g.mode != _lib.TAP_LINEAR else g.M
         abytes = (2.0 * src_rows * g.C1 + 2.0 * g.M * g.C2 + 2.0 * g.N * K * (2 if dw is not None else 1) +
                   float(g.M) * n_out * ((4 if g.out_dtype == torch.float32 else 2) + (4 if g.residual is not None else 0)))
-        with self._Prof("tapgemm", 2.0 * g.M * g.N * K, meta, abytes):
+        k_alg = g.alg_k or K
+        assert 0 < k_alg <= K
+        with self._Prof("tapgemm", 2.0 * g.M * g.N * k_alg, meta, (abytes, 2.0 * g.M * g.N * K * (2 if dw is not None else 1))):
             rc = self.lib.vgen_tapgemm(C.byref(a), self._stream(A))
         _lib.check(rc, "vgen_tapgemm")
         if cs is not None:
@@ -456,6 +462,35 @@ class HipBackend:
             _ptr(x_units) if replicate else None, G if replicate else 0, B * unit, unit, self._stream(x_units))
         _lib.check(rc, "vgen_cfg_ddim_step_units")
         return xt_1, x0
+
+    def ddim_update_strided(self, xt_rows, y, u, coef_tab, t_idx, guide, use_guide, mean_type, out_rows=None, x0_out=None,
+                            rep_units=None, G=0, C_lat=0):
+        """vgen_cfg_ddim_step_units with its row addressing exposed (vgen_amd/parallel.py, the partitioned step): x_t of
+        batch element b = xt_rows[b] — a view whose rows are contiguous but may be strided (every W-th prompt) —, y / u
+        contiguous [B, ...] (a rank's block of the all-gathered buffer), coefficient row coef_tab[t_idx[b]]; x_{t-1} goes
+        to the strided view `out_rows` OR (rep_units) into the latent channels of the G slots of a session's x_units;
+        x0 to the contiguous `x0_out`."""
+        B = xt_rows.shape[0]
+        per_b = xt_rows[0].numel()
+        assert xt_rows.dtype == torch.float32 and xt_rows[0].is_contiguous()
+        for t_ in (y, u, x0_out):
+            assert t_ is None or (t_.dtype == torch.float32 and t_.is_contiguous() and t_.numel() == B * per_b)
+        assert coef_tab.dtype == torch.float32 and coef_tab.is_contiguous() and coef_tab.shape[-1] == 7
+        assert t_idx.dtype == torch.int64 and t_idx.is_contiguous() and t_idx.numel() == B
+        assert (out_rows is None) != (rep_units is None)
+        if out_rows is not None:
+            assert out_rows.dtype == torch.float32 and out_rows.shape[0] == B and out_rows[0].is_contiguous()
+            rep, nrep, gs, bs = out_rows, 1, 0, (out_rows.stride(0) if B > 1 else per_b)
+        else:
+            assert rep_units.dtype == torch.float32 and rep_units.is_contiguous() and rep_units.shape[0] == G * B
+            assert C_lat * rep_units[0, 0].numel() == per_b
+            unit = rep_units[0].numel()
+            rep, nrep, gs, bs = rep_units, G, B * unit, unit
+        rc = self.lib.vgen_cfg_ddim_step_units(
+            _ptr(xt_rows), xt_rows.stride(0) if B > 1 else per_b, _ptr(y), _ptr(u), None, _ptr(coef_tab), _ptr(t_idx),
+            float(guide), int(use_guide), int(mean_type), B, per_b, None, _ptr(x0_out), _ptr(rep), nrep, gs, bs,
+            self._stream(xt_rows))
+        _lib.check(rc, "vgen_cfg_ddim_step_units")
 
     def lowfreq_filter(self, x, nimg, H, W, scale):
         assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[0] == nimg * H * W

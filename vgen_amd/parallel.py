@@ -70,9 +70,15 @@ def _slice_kwargs(kw, ps, P):
     return out
 
 
+# r04 switch: model -> all-gather -> fused update of a partitioned DDIM step as ONE launch sequence, captured as one
+# hipGraph per step when the group's backend is nccl (= RCCL); default off until it has run on a multi-GPU node
+_GRAPH_COLLECTIVE = os.environ.get("VGEN_PARTITION_GRAPH") == "1"
+
+
 class UnitPartition:
-    def __init__(self, group=None):
+    def __init__(self, group=None, graph_collective=None):
         self.group = group
+        self.graph_collective = _GRAPH_COLLECTIVE if graph_collective is None else bool(graph_collective)
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         from .session import SessionCache
@@ -214,3 +220,108 @@ class UnitPartition:
             local = torch.stack([outs[u] for u in mine]) if mine else \
                 xt.new_zeros((0,) + unit_shape, dtype=torch.float32)
         return self.gather_grouped(local, P, G)
+
+    # -- r04: the whole partitioned DDIM step as one launch sequence --------------------------------------------------
+    def fused_layout(self, P: int, G: int):
+        """(owner rank -> list of prompts it owns in slot order) when the gathered buffer splits into per-rank blocks the
+        update kernel can address directly ('prompt' layout: rank r's block is [y of its P/W prompts | u of them]; or ONE
+        prompt whose G = W = 2 branches sit on two ranks), else None (the eager path handles everything)."""
+        W = self.world
+        if G == 2 and self.layout(P, G) == "prompt":
+            return "prompt"
+        if P == 1 and G == 2 and W == 2:
+            return "pair"
+        return None
+
+    def ddim_step(self, model, xt, t, model_kwargs, coef_tab, guide, mean_type, num_timesteps):
+        """One classifier-free-guidance DDIM step (eta = 0) of P prompts over the ranks as ONE launch sequence on the
+        compute stream:
+            local units' UNet forward -> ONE all_gather_into_tensor of the unit outputs -> fused CFG + DDIM update of ALL
+            prompts (redundantly on every rank, y / u read straight from the gathered buffer, coefficients gathered by t on
+            the device) -> x_{t-1} [P, ...] and the local units' latent slots for the next step.
+        r03 ran per step: graph replay, eager all-gather, index_select, ~10 tiny torch launches for the coefficient rows,
+        eager update kernel.  With the nccl (= RCCL) backend the sequence is captured as ONE hipGraph; with gloo (CPU tests,
+        the one-device functional test) the same sequence runs eagerly.  Returns (x_{t-1}, x0) — the session's own buffers,
+        valid until the next step; passing that x_{t-1} back in skips the input copies — or None when the step does not fit (layout, kwargs, dtype):
+        the caller then takes the eager path."""
+        G = len(model_kwargs)
+        P = xt.shape[0]
+        kind = self.fused_layout(P, G)
+        inner = getattr(model, "module", model)
+        if kind is None or xt.dim() != 5 or not hasattr(inner, "_prepare_units") or t.dtype != torch.long:
+            return None
+        from . import ops
+        W, dev = self.world, xt.device
+        if kind == "prompt":
+            ps = [p for p in range(P) if p % W == self.rank]
+            idx, sub = self._local_kwargs(model_kwargs, ps, P, dev)
+            sess = self.sessions.get(inner, (len(ps),) + tuple(xt.shape[1:]), dev, sub, t.dtype, num_timesteps)
+            nloc = len(ps)
+        else:       # "pair": session unit index g * P + p = g — cond on rank 0, uncond on rank 1
+            idx, nloc = None, 1
+            sess = self.sessions.get(inner, tuple(xt.shape), dev, list(model_kwargs), t.dtype, num_timesteps,
+                                     units=[self.rank])
+        if sess is None:
+            return None
+        S = self.slots(P * G)
+        st = sess._static.get("pstep")
+        if st is None:
+            lat = (sess.C_lat, sess.F, sess.H, sess.W)
+            f32 = dict(dtype=torch.float32, device=dev)
+            st = dict(allb=torch.empty((W * S,) + tuple(sess.out.shape[1:]), **f32), x_all=torch.zeros((P,) + lat, **f32),
+                      x0_blk=torch.empty((P,) + lat, **f32), t_ord=torch.zeros((P,), dtype=torch.long, device=dev))
+            sess._static["pstep"] = st
+        # ---- per-step inputs (outside the captured sequence): t in block order; x_t unless it is last step's x_{t-1} ----
+        if kind == "prompt":
+            st["t_ord"].view(W, nloc).copy_(t.view(nloc, W).t())        # t_ord[r, j] = t[r + W j]
+            sess.t_units.view(G, nloc).copy_(st["t_ord"].view(W, nloc)[self.rank])
+        else:
+            st["t_ord"].copy_(t)
+            sess.t_units.copy_(t)
+        if xt is not st["x_all"]:
+            st["x_all"].copy_(xt)
+            if kind == "prompt":
+                sess.x_units.view(G, nloc, *sess.x_units.shape[1:])[:, :, :sess.C_lat].copy_(xt.float().index_select(0, idx))
+            else:
+                sess.x_units[:, :sess.C_lat].copy_(xt.float())
+        sess._last_out = None
+        be = ops.backend()
+        collective = self.world > 1 or _FORCE_COLLECTIVE
+        nccl = dist.is_initialized() and dist.get_backend(self.group) == "nccl"
+
+        def launches():
+            sess._model_launches()
+            if collective:
+                dist.all_gather_into_tensor(st["allb"], sess.out, group=self.group)
+                allb = st["allb"]
+            else:
+                allb = sess.out
+            x_all, x0b, t_ord = st["x_all"], st["x0_blk"], st["t_ord"]
+            # x_t -> x_{t-1} IN PLACE in x_all (every element is read and written by the same thread: the kernel's `rep` may
+            # alias `xt`): x_all is the next step's x_t on every rank.  The local units' latent slots are written first,
+            # by the same arithmetic on the still unmodified x_t.
+            if kind == "prompt":
+                # rank r's block of the gathered buffer = [y of prompts r, r + W, ... | u of the same]: the update of those
+                # prompts reads x_t and writes x_{t-1} at row stride W (the update kernel addresses rows by stride)
+                for r in range(W):
+                    blk = allb[r * S:(r + 1) * S]
+                    tr = t_ord[r * nloc:(r + 1) * nloc]
+                    if r == self.rank:
+                        be.ddim_update_strided(x_all[r::W], blk[:nloc], blk[nloc:2 * nloc], coef_tab, tr, guide, True,
+                                               mean_type, rep_units=sess.x_units, G=G, C_lat=sess.C_lat)
+                    be.ddim_update_strided(x_all[r::W], blk[:nloc], blk[nloc:2 * nloc], coef_tab, tr, guide, True, mean_type,
+                                           out_rows=x_all[r::W], x0_out=x0b[r * nloc:(r + 1) * nloc])
+            else:
+                be.ddim_update_strided(x_all, allb[0:1], allb[1:2], coef_tab, t_ord, guide, True, mean_type,
+                                       rep_units=sess.x_units, G=1, C_lat=sess.C_lat)
+                be.ddim_update_strided(x_all, allb[0:1], allb[1:2], coef_tab, t_ord, guide, True, mean_type,
+                                       out_rows=x_all, x0_out=x0b)
+
+        key = ("pddim", id(coef_tab), float(guide), int(mean_type))
+        sess._static[("tab",) + key] = coef_tab
+        sess._run(key, launches, graph_ok=(nccl or not collective))
+        if kind == "prompt" and W > 1:
+            x0 = st["x0_blk"].view(W, nloc, *st["x0_blk"].shape[1:]).transpose(0, 1).reshape(st["x_all"].shape)
+        else:
+            x0 = st["x0_blk"]
+        return st["x_all"], x0

@@ -33,6 +33,7 @@ import torch
 from . import ops
 
 _GRAPH_ON = os.environ.get("VGEN_GRAPH", "1") != "0"
+_REBIND_ON = os.environ.get("VGEN_SESSION_REBIND", "1") != "0"    # switch: 0 = every new prompt builds + captures its own session
 
 
 class Unkeyable(Exception):
@@ -65,6 +66,23 @@ def _kw_key(kwargs_list):
     return tuple(tuple((k, _val_key(kw[k])) for k in sorted(kw)) for kw in kwargs_list)
 
 
+def _val_struct(v):
+    """_val_key without the identity: what two prompts' kwarg values must share for one captured launch sequence."""
+    if torch.is_tensor(v):
+        return ("T", tuple(v.shape), v.dtype, str(v.device))
+    if isinstance(v, (list, tuple)):
+        return ("L", type(v).__name__) + tuple(_val_struct(e) for e in v)
+    if isinstance(v, dict):
+        return ("D",) + tuple((str(k), _val_struct(v[k])) for k in sorted(v, key=str))
+    if v is None or isinstance(v, (bool, int, float, str)):
+        return ("S", type(v).__name__, v)
+    return ("O", type(v).__name__)
+
+
+def _kw_struct(kwargs_list):
+    return tuple(tuple((k, _val_struct(kw[k])) for k in sorted(kw)) for kw in kwargs_list)
+
+
 class UnitSession:
     def __init__(self, model, shape, device, kwargs_list, t_dtype=torch.long, num_timesteps=None,
                  units: Optional[Sequence[int]] = None):
@@ -74,37 +92,20 @@ class UnitSession:
         self.G = len(kwargs_list)
         self.B, self.C_lat, self.F, self.H, self.W = shape
         self.device = torch.device(device)
-        self.kwargs_ref = [dict(kw) for kw in kwargs_list]         # keeps the keyed tensors alive (ids stay unique)
         if model._packed is None:
             model.pack()
-        prep = model._prepare_units(tuple(shape), self.device, kwargs_list)
-        if prep is None:
-            raise ValueError("kwarg sets cannot share one UNet batch")
         U = self.G * self.B
         sel = list(range(U)) if units is None else list(units)
         self.units = sel
         self.full = units is None
         nU = len(sel)
-        idx = torch.tensor(sel, dtype=torch.long, device=self.device)
+        self._idx = torch.tensor(sel, dtype=torch.long, device=self.device)
         C_stem = model._stem_channels()
         self.x_units = torch.zeros((nU, C_stem, self.F, self.H, self.W), dtype=torch.float32, device=self.device)
-        if prep["extra"] is not None:
-            assert prep["extra"].shape[1] == C_stem - self.C_lat
-            self.x_units[:, self.C_lat:] = prep["extra"].to(self.device).float()[idx]
-        else:
-            assert C_stem == self.C_lat, (C_stem, self.C_lat)
-        ctx = prep["ctx"].to(self.device)
-        self.per_frame = bool(prep["per_frame"])
-        if self.per_frame:
-            ctx = ctx.view(U, self.F, *ctx.shape[1:])[idx].reshape(nU * self.F, *ctx.shape[1:])
-        else:
-            ctx = ctx[idx]
-        self.Lctx = ctx.shape[1]
-        self.kv = model._context_kv(ctx.contiguous(), self.device) if nU else None   # prompt constant: once
-        self.fps = None if prep["fps"] is None else prep["fps"].to(self.device)[idx].contiguous()
-        # classifier-free guidance: the G sets share the latent; when their stem channels / fps agree too, the layers
-        # ahead of the first cross-attention are evaluated once (UNetSD_T2VBase._body, shared_groups)
-        self.shared = model.shared_prefix_groups(prep, self.G, self.B) if self.full else 1
+        self.kv = self.fps = None
+        self.per_frame, self.Lctx, self.shared = False, 0, 1
+        if not self._bind(kwargs_list, first=True):
+            raise ValueError("kwarg sets cannot share one UNet batch")
         self.t_units = torch.zeros((nU,), dtype=t_dtype, device=self.device)
         self.out = torch.empty((nU, model.out_dim, self.F, self.H, self.W), dtype=torch.float32, device=self.device)
         # time-embedding table: integer timesteps of a known schedule length, no fps term inside the SiLU
@@ -122,6 +123,52 @@ class UnitSession:
         self.x0 = torch.empty_like(self.xt_1)
         self._last_out = None       # the tensor handed to the caller by the previous fused step
         self._bidx = None
+
+    # -- the prompt-dependent state ------------------------------------------------------------------
+    def _bind(self, kwargs_list, first=False):
+        """Everything that depends on the PROMPT (condition-stem channels, the units' context -> K/V rows of every
+        cross-attention block, fps) written into the session's static buffers.  first=False re-binds a live session to
+        the kwarg sets of ANOTHER prompt of the same structure (r04): the captured graphs read these buffers by address,
+        so a new prompt costs one K/V GEMM and two copies instead of an eager warm-up pass plus a re-capture of ~900
+        launches — what a 4-step LCM loop or a multi-prompt serving run would otherwise pay per video.  Returns False
+        (nothing modified that a graph reads) when the new sets do not fit the captured launch sequence."""
+        model, dev = self.model, self.device
+        prep = model._prepare_units((self.B, self.C_lat, self.F, self.H, self.W), dev, kwargs_list)
+        if prep is None:
+            return False
+        U, nU, idx = self.G * self.B, len(self.units), self._idx
+        C_stem = model._stem_channels()
+        extra = prep["extra"]
+        if (extra is None) != (C_stem == self.C_lat) or (extra is not None and extra.shape[1] != C_stem - self.C_lat):
+            assert not first, (C_stem, self.C_lat)
+            return False
+        ctx = prep["ctx"].to(dev)
+        per_frame = bool(prep["per_frame"])
+        if per_frame:
+            ctx = ctx.view(U, self.F, *ctx.shape[1:])[idx].reshape(nU * self.F, *ctx.shape[1:])
+        else:
+            ctx = ctx[idx]
+        shared = model.shared_prefix_groups(prep, self.G, self.B) if self.full else 1
+        fps = None if prep["fps"] is None else prep["fps"].to(dev)[idx].contiguous()
+        if not first:
+            # the launch sequence of the captured graphs is a function of these: a prompt that changes them needs its own session
+            if per_frame != self.per_frame or ctx.shape[1] != self.Lctx or shared != self.shared or \
+                    (fps is None) != (self.fps is None):
+                return False
+        if extra is not None:
+            self.x_units[:, self.C_lat:] = extra.to(dev).float()[idx]
+        kv = model._context_kv(ctx.contiguous(), dev) if nU else None   # prompt constant: once per prompt
+        if first:
+            self.kv, self.fps = kv, fps
+            self.per_frame, self.Lctx, self.shared = per_frame, ctx.shape[1], shared
+        else:
+            if kv is not None:
+                self.kv.copy_(kv)
+            if fps is not None:
+                self.fps.copy_(fps)
+        self.kwargs_ref = [dict(kw) for kw in kwargs_list]         # keeps the keyed tensors alive (ids stay unique)
+        self._last_out = None
+        return True
 
     # -- inputs --------------------------------------------------------------------------------------
     def load(self, xt, t):
@@ -149,9 +196,10 @@ class UnitSession:
             emb = m._embed(self.t_units, self.fps, nU, self.device)
         m._body(self.x_units, emb, self.kv, self.Lctx, self.per_frame, out=self.out, shared_groups=self.shared)
 
-    def _run(self, key, launches):
-        """Run `launches()` eagerly (first call: warms the allocator, JIT-free) and from then on as a graph."""
-        if not self.use_graph:
+    def _run(self, key, launches, graph_ok=True):
+        """Run `launches()` eagerly (first call: warms the allocator, JIT-free) and from then on as a graph.
+        graph_ok=False: this launch sequence cannot be captured (a host-side collective inside it): always eager."""
+        if not self.use_graph or not graph_ok:
             launches()
             return
         g = self._graphs.get(key)
@@ -217,13 +265,18 @@ class UnitSession:
 
 
 class SessionCache:
-    """Small LRU of UnitSessions.  The engines build new kwarg tensors per prompt, so every prompt is a new session and
-    an old prompt's session (its graphs + their memory pool) is dead weight: capacity 2 = the prompt in flight plus
-    one sibling (e.g. the inversion pass and the CFG pass of the SR600 stage); `clear()` between prompts frees both."""
+    """Small LRU of UnitSessions.  The engines build new kwarg tensors per prompt, so every prompt is a new key:
+    capacity 2 = the prompt in flight plus one sibling (e.g. the inversion pass and the CFG pass of the SR600 stage);
+    `clear()` frees both.  r04: when the cache is full and a new prompt has the STRUCTURE of a cached session (same
+    model / weights epoch / latent shape / unit set, same kwarg names with tensors of the same shapes), the least
+    recently used such session is RE-BOUND to the new prompt (UnitSession._bind) instead of evicted and rebuilt: its
+    graphs and memory pool live on, the new prompt pays one K/V GEMM — not a warm-up pass and a capture."""
 
     def __init__(self, capacity=2):
         self.capacity = capacity
         self._items = {}
+        self._struct = {}           # key -> structure key of its session
+        self.rebinds = 0
 
     def get(self, model, shape, device, kwargs_list, t_dtype, num_timesteps, units=None):
         inner = getattr(model, "module", model)              # DistributedDataParallel wrapper of the engines
@@ -233,21 +286,36 @@ class SessionCache:
             kkey = _kw_key(kwargs_list)
         except Unkeyable:
             return None                                      # no stable identity: evaluate without a session
-        key = (id(inner), inner._epoch, tuple(shape), str(device), kkey, t_dtype, num_timesteps,
-               None if units is None else tuple(units), ops.backend().name)
+        base = (id(inner), inner._epoch, tuple(shape), str(device), t_dtype, num_timesteps,
+                None if units is None else tuple(units), ops.backend().name)
+        key = base + (kkey,)
         s = self._items.pop(key, None)
+        skey = self._struct.pop(key, None)
         if s is None:
-            try:
-                s = UnitSession(inner, tuple(shape), device, kwargs_list, t_dtype, num_timesteps, units)
-            except ValueError:
-                return None
-            while len(self._items) >= self.capacity:
-                self._items.pop(next(iter(self._items)))
+            skey = base + (_kw_struct(kwargs_list),)
+            if len(self._items) >= self.capacity and _REBIND_ON:
+                for old in list(self._items):                   # insertion order = least recently used first
+                    if self._struct.get(old) == skey and self._items[old]._bind(kwargs_list):
+                        s = self._items.pop(old)
+                        self._struct.pop(old, None)
+                        self.rebinds += 1
+                        break
+            if s is None:
+                try:
+                    s = UnitSession(inner, tuple(shape), device, kwargs_list, t_dtype, num_timesteps, units)
+                except ValueError:
+                    return None
+                while len(self._items) >= self.capacity:
+                    old = next(iter(self._items))
+                    self._items.pop(old)
+                    self._struct.pop(old, None)
         self._items[key] = s
+        self._struct[key] = skey
         return s
 
     def clear(self):
         self._items.clear()
+        self._struct.clear()
 
 
 def eval_units(cache, partition, model, xt, t, kwargs_list, num_timesteps=None):
