@@ -425,6 +425,7 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--no-scaling-model", action="store_true")
     ap.add_argument("--partition", action="store_true",
                     help="use the multi-GPU code path (UnitPartition: session over the local units + eager "
                          "gather/update) even at --gpus 1")
@@ -605,6 +606,36 @@ def main():
             if val is not None:      # how far the reference's OWN autocast forward lands from its fp32 forward (committed fixture)
                 res["parity"]["committed_reference_own_autocast_rel_l2"] = val
 
+    # ---- what a 2-GPU split of ONE video can reach (north_star: "cond on GPU 0, uncond on GPU 1") ----------------
+    # A unit-major rank runs ONE unit's forward + the update; the pair step above runs two units in one batch.  Their ratio
+    # bounds the strong scaling of a single video on 2 GPUs before any collective cost; weak scaling (P = N prompts, what
+    # --gpus N measures) keeps whole pairs per rank.  No 1 -> 8 curve has been measured on hardware (the driver's to run).
+    if rank == 0 and world == 1 and part is None and args.config == "t2v" and G == 2 and not args.no_scaling_model:
+        from vgen_amd.session import SessionCache
+        sc = SessionCache(capacity=1)
+        s1 = sc.get(model, tuple(xt0.shape), dev, list(kw), torch.long, 1000, units=[0])
+        tt = timer.t_of(0)
+        for _ in range(3):
+            s1.eval(xt0, tt)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(10):
+            s1.eval(xt0, tt)
+        torch.cuda.synchronize()
+        unit_ms = 1e2 * (time.perf_counter() - t1)
+        pair_ms = 1e3 * dt_s / args.steps
+        res["scaling_model"] = {
+            "single_unit_forward_ms": round(unit_ms, 3), "pair_step_ms": round(pair_ms, 3),
+            "predicted_2gpu_strong_scaling_bound_one_video": round(pair_ms / unit_ms, 3),
+            "note": "measured at N = 1: one unit's forward (what each rank of the cond | uncond split runs) vs the 2-unit step; "
+                    "an upper bound before the all-gather; weak scaling (--gpus N: N prompts) is not bounded by it; "
+                    "no multi-GPU curve has been measured",
+            "launch_line": "python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 "
+                           "--master-port 29500 bench.py --gpus N --steps 20 --warmup 5 [--graph-collective]"}
+        del s1, sc
+        gc.collect()
+        torch.cuda.empty_cache()
+
     # ---- roofline of the dominant kernel (instrumented eager pass, same step) ----------------------
     if rank == 0 and not args.no_roofline:
         d0 = DiffusionDDIM(**DDIM)
@@ -720,6 +751,56 @@ def main():
                       "precision": vae.precision}
         if args.vae_size == "256x448":
             res["vae"]["tflops_per_s"] = round(fps * VAE_DEC_TFLOP, 2)
+            # the 720p frames of BASELINE configs 3 / 5 (SR600 / I2VGen decode and the SR600 stage's encode), 2 frames a call
+            z7 = torch.randn(2, 4, 90, 160, device=dev) / 0.18215 * 0.2
+            x7 = torch.rand(2, 3, 720, 1280, device=dev) * 2 - 1
+            for fn, arg, key in ((vae.decode, z7, "decode_720p_frames_per_sec"), (vae.encode_firsr_stage, x7, "encode_720p_frames_per_sec")):
+                fn(arg)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for _ in range(2):
+                    fn(arg)
+                torch.cuda.synchronize()
+                res["vae"][key] = round(4 / (time.perf_counter() - t1), 2)
+        if vae.precision != "fast" and args.vae_size == "256x448":
+            # the single-pass VAE next to it: the north-star states a tolerance for the UNet only, and this mode (decode 1.37e-3
+            # from the reference's fp32 decode) is already closer than the reference's own autocast arithmetic (1.90e-3)
+            with torch.device(dev):
+                vf = AutoencoderKL(ddconfig=VAE_SD, embed_dim=4, compute_dtype=args.dtype, precision="fast")
+            vf.eval()
+            randomize_(vf, 1)
+            for _ in range(3):
+                vf.decode(z)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(nrep):
+                vf.decode(z)
+            torch.cuda.synchronize()
+            res["vae"]["decode_frames_per_sec_precision_fast"] = round(2 * nrep / (time.perf_counter() - t1), 2)
+            del vf
+        if args.dump_shapes:
+            ops.KERNEL_PROFILE = []
+            torch.cuda.synchronize()
+            torch.cuda._sleep(int(2e8))
+            import vgen_amd.session as _vs
+            _g_on, _vs._GRAPH_ON = _vs._GRAPH_ON, False         # per-launch events need the eager launch sequence
+            vae.decode(z)
+            _vs._GRAPH_ON = _g_on
+            torch.cuda.synchronize()
+            vrec = ops.KERNEL_PROFILE
+            ops.KERNEL_PROFILE = None
+            agg = {}
+            for r in vrec:
+                a = agg.setdefault((r[0],) + tuple(r[4]), [0, 0.0, 0.0])
+                a[0] += 1
+                a[1] += r[1].elapsed_time(r[2])
+                a[2] += r[3]
+            rows = sorted(([list(map(str, k)), v[0], round(v[1], 4), round(v[2] / (v[1] * 1e-3) / 1e9, 1)] for k, v in agg.items()),
+                          key=lambda r: -r[2])
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", f"vae_shapes_{args.vae_size}_{vae.precision}.json"), "w") as f:
+                json.dump({"cols": ["(op,shape...)", "launches", "ms", "GFLOP/s or GB/s"], "rows": rows,
+                           "total_ms": round(sum(v[1] for v in agg.values()), 3), "frames": 2}, f, indent=0)
         if not args.no_e2e and world == 1 and part is None and args.config == "t2v":
             # the engine's whole job for one prompt (inference_text2video_entrance.py:194-217): 50-step
             # ddim_sample_loop + 16 frames decoded 2 at a time to uint8 video

@@ -155,13 +155,30 @@ class EmuBackend:
             return _strided(t, (no, ni, g.heads, n, 64), (bo, bi, 64, rs, 1)).float()
 
         q, k, v = seqs(g.q, g.q_s, g.nq), seqs(g.k, g.k_s, g.nk), seqs(g.v, g.v_s, g.nk)
-        sc = q @ k.transpose(-1, -2) * g.scale
-        if getattr(g, "causal", False):
-            sc = sc.masked_fill(torch.ones(g.nq, g.nk, dtype=torch.bool).triu(1), float("-inf"))
-        w = torch.softmax(sc, dim=-1)
-        o = w @ v
         rs, bo, bi = g.o_s
-        _strided(g.out, (no, ni, g.heads, g.nq, 64), (bo, bi, 64, rs, 1)).copy_(o.to(g.out.dtype))
+        ov = _strided(g.out, (no, ni, g.heads, g.nq, 64), (bo, bi, 64, rs, 1))
+        # sequences are independent: evaluate the outer batch in chunks of <= ~2 GB of fp32 scores (the 14 400-token
+        # self-attention of a 32-frame 720p latent is 133 GB at once)
+        per = ni * g.heads * g.nq * g.nk * 4
+        step = max(1, int(2e9 // max(per, 1)))
+        for a in range(0, no, step):
+            sc = q[a:a + step] @ k[a:a + step].transpose(-1, -2) * g.scale
+            if getattr(g, "causal", False):
+                sc = sc.masked_fill(torch.ones(g.nq, g.nk, dtype=torch.bool).triu(1), float("-inf"))
+            ov[a:a + step].copy_((torch.softmax(sc, dim=-1) @ v[a:a + step]).to(g.out.dtype))
+        return g.out
+
+    def attention_d512(self, g):
+        # vgen_attention_d512: one head of 512 channels; v is V^T [nbatch, 512, >= nk]
+        assert g.heads == 1 and g.inner == 1
+        nb = g.nbatch
+        q = _strided(g.q, (nb, g.nq, 512), (g.q_s[1], g.q_s[0], 1)).float()
+        k = _strided(g.k, (nb, g.nk, 512), (g.k_s[1], g.k_s[0], 1)).float()
+        vt = _strided(g.v, (nb, 512, g.nk), (g.v_s[1], g.v_s[0], 1)).float()
+        ov = _strided(g.out, (nb, g.nq, 512), (g.o_s[1], g.o_s[0], 1))
+        for i in range(nb):
+            w = torch.softmax(q[i] @ k[i].t() * g.scale, dim=-1)
+            ov[i].copy_((w @ vt[i].t()).to(g.out.dtype))
         return g.out
 
     def softmax_rows(self, S, cols, scale, dt, out=None):

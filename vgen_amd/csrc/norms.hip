@@ -189,13 +189,17 @@ __device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, flo
   n = nt;
 }
 
-__global__ __launch_bounds__(256) void gn_finalize_cs_kernel(const float* __restrict__ cs1, int C1,
+// r04: NT = 1024 for the 5-D norms of the big levels (448 slabs x 10..40 channels = 4.5 K - 18 K items per group: 18 - 70
+// dependent L2 round trips per thread at 256 threads were most of this launch's ~10 us; 68 such launches per step).
+template <int NT>
+__global__ __launch_bounds__(NT) void gn_finalize_cs_kernel(const float* __restrict__ cs1, int C1,
                                                              const float* __restrict__ cs2, int C2,
                                                              int64_t S, int groups, float eps,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
                                                              float* __restrict__ stat) {
-  __shared__ float red[4][3];
+  constexpr int NW = NT / 64;
+  __shared__ float red[NW][3];
   __shared__ float mr[2];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int grp = blockIdx.x;
@@ -218,17 +222,17 @@ __global__ __launch_bounds__(256) void gn_finalize_cs_kernel(const float* __rest
     }
   };
   int it = tid;
-  for (; it + 3 * 256 < items; it += 4 * 256) {
+  for (; it + 3 * NT < items; it += 4 * NT) {
     float sm[4], sq[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) fetch(it + u * 256, sm[u], sq[u]);
+    for (int u = 0; u < 4; ++u) fetch(it + u * NT, sm[u], sq[u]);
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const float mb = sm[u] * (1.0f / 64.f);
       chan_merge(n, mean, m2, 64.f, mb, fmaxf(sq[u] - sm[u] * mb, 0.f));
     }
   }
-  for (; it < items; it += 256) {
+  for (; it < items; it += NT) {
     float sm, sq;
     fetch(it, sm, sq);
     const float mb = sm * (1.0f / 64.f);
@@ -258,14 +262,14 @@ __global__ __launch_bounds__(256) void gn_finalize_cs_kernel(const float* __rest
   __syncthreads();
   if (tid == 0) {
     float N = red[0][0], M = red[0][1], Q = red[0][2];
-    for (int k = 1; k < 4; ++k) chan_merge(N, M, Q, red[k][0], red[k][1], red[k][2]);
+    for (int k = 1; k < NW; ++k) chan_merge(N, M, Q, red[k][0], red[k][1], red[k][2]);
     const float var = N > 0.f ? Q / N : 0.f;
     mr[0] = M;
     mr[1] = 1.0f / sqrtf(var + eps);
   }
   __syncthreads();
   const int C = C1 + C2;
-  for (int j = tid; j < cpg; j += 256) {
+  for (int j = tid; j < cpg; j += NT) {
     const int c = grp * cpg + j;
     const float a = gamma[c] * mr[1];
     stat[(nb * C + c) * 2 + 0] = a;
@@ -816,8 +820,13 @@ static int groupnorm_impl(const float* x1, int32_t C1, const float* cs1, const f
   dim3 grid((unsigned)ns, (unsigned)nb);
   int rc;
   if (cs1 != nullptr) {
-    hipLaunchKernelGGL(gn_finalize_cs_kernel, dim3((unsigned)groups, (unsigned)nb), dim3(256), 0, s, cs1, C1,
-                       cs2, C2, S, groups, eps, gamma, beta, stat);
+    if ((S / 64) * (C / groups) > 2048) {
+      hipLaunchKernelGGL(gn_finalize_cs_kernel<1024>, dim3((unsigned)groups, (unsigned)nb), dim3(1024), 0, s, cs1, C1,
+                         cs2, C2, S, groups, eps, gamma, beta, stat);
+    } else {
+      hipLaunchKernelGGL(gn_finalize_cs_kernel<256>, dim3((unsigned)groups, (unsigned)nb), dim3(256), 0, s, cs1, C1,
+                         cs2, C2, S, groups, eps, gamma, beta, stat);
+    }
     rc = vgen_check_launch("gn_finalize_cs");
     if (rc) return rc;
   } else {

@@ -13,6 +13,8 @@ scores-GEMM -> row softmax kernel -> PV-GEMM.
 """
 from __future__ import annotations
 
+import os
+
 import collections
 import logging
 
@@ -175,7 +177,11 @@ class AutoencoderKL(nn.Module):
         self.precision = precision or "fast"      # "high": weights as hi + lo operand pairs (vgen_amd/unet.py)
         assert self.precision in ("fast", "high")
         self._packed = None
-        self._attn_qb = None          # query-block override of the mid attention (tests force several blocks)
+        self._attn_qb = None          # query-block override of the legacy (GEMM) mid attention (tests force several blocks)
+        # r04: the mid attention as ONE fused launch over all frames of a chunk (vgen_attention_d512); False = the r03
+        # sequence per frame and query block (scores GEMM -> fp32 S -> row softmax -> PV GEMM), kept as a cross-check
+        self._attn_fused = os.environ.get("VGEN_VAE_ATTN_FUSED", "1") != "0"
+        self._graphs = {}             # (kind, input shape, device) -> captured launch sequence of a decode / encode chunk
         if pretrained is not None:
             self.init_from_ckpt(pretrained, ignore_keys=ignore_keys)
 
@@ -189,15 +195,57 @@ class AutoencoderKL(nn.Module):
         logging.info(f"Restored from {path}")
 
     def _apply(self, fn, *a, **k):
-        self._packed = None
+        self.invalidate()
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
-        self._packed = None
+        self.invalidate()
         return super().load_state_dict(*a, **k)
 
     def invalidate(self):
         self._packed = None
+        self._graphs = {}
+
+    # -- r04: a decode / encode chunk is ONE hipGraph replay ------------------------------------------------------
+    _GRAPH_SHAPES = 2             # captured input shapes kept per model (each holds a chunk's peak activations)
+
+    def _graphed(self, kind, rows_fn, x):
+        """rows_fn(x) -> (rows, n, H, W) through a captured graph keyed on (kind, x.shape): the engines decode a video as
+        F / decoder_bs identical chunks (inference_text2video_entrance.py:208-217) — ~110 launches each, many of them a few
+        microseconds long at the low-resolution levels.  First call of a shape runs eagerly (warms the allocator), the
+        second captures, later ones copy the input into the graph's static buffer and replay.  The returned rows live in
+        the graph's memory pool: valid until the next call of the same shape (every caller consumes them at once).
+        VGEN_GRAPH=0, CPU tensors (the tests' ABI emulator) and capture failures take the eager path."""
+        from .session import _GRAPH_ON
+        if not _GRAPH_ON or x.device.type != "cuda":
+            return rows_fn(x)
+        key = (kind, tuple(x.shape), str(x.device), self._attn_qb, self._attn_fused)
+        st = self._graphs.get(key)
+        if st is None:
+            while len(self._graphs) >= self._GRAPH_SHAPES:
+                self._graphs.pop(next(iter(self._graphs)))
+            self._graphs[key] = {"calls": 1}
+            return rows_fn(x)
+        if "graph" not in st:
+            if st.get("failed"):
+                return rows_fn(x)
+            xin = x.float().contiguous().clone()
+            torch.cuda.synchronize(x.device)
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    out = rows_fn(xin)
+            except Exception as ex:             # noqa: BLE001 — capture is an optimisation: stay correct, say so
+                import warnings
+                warnings.warn(f"AutoencoderKL: hipGraph capture of {kind} failed ({type(ex).__name__}: {ex}); running eagerly")
+                torch.cuda.synchronize(x.device)
+                st["failed"] = True
+                return rows_fn(x)
+            st.update(graph=g, xin=xin, out=out)
+        else:
+            st["xin"].copy_(x)
+        st["graph"].replay()
+        return st["out"]
 
     # -- packing ---------------------------------------------------------------------------------
     @torch.no_grad()
@@ -228,7 +276,10 @@ class AutoencoderKL(nn.Module):
                     "qk": (pack_linear(torch.cat([m.q.weight, m.k.weight], 0), dt),
                            torch.cat([_f32(m.q.bias), _f32(m.k.bias)]).contiguous()),
                     "v": pack_linear(m.v.weight, dt), "vb": _f32(m.v.bias),
-                    "o": (pack_linear(m.proj_out.weight, dt), _f32(m.proj_out.bias))}
+                    "o": (pack_linear(m.proj_out.weight, dt), _f32(m.proj_out.bias)),
+                    # fused attention: softmax rows sum to 1, so the value bias passes through the attention unchanged
+                    # and is folded (fp32) into the output projection's bias: Wo (P V + 1 vb^T) + bo = Wo P V + (Wo vb + bo)
+                    "ob_fused": (_f32(m.proj_out.bias) + _f32(m.proj_out.weight).reshape(m.c, m.c) @ _f32(m.v.bias)).contiguous()}
             elif isinstance(m, _ResampleP):
                 P[name] = (pack_conv3x3(m.conv.weight, dt), _f32(m.conv.bias))
         for side in ("encoder", "decoder"):
@@ -254,7 +305,13 @@ class AutoencoderKL(nn.Module):
             Ho, Wo = Hi << ups, Wi << ups
         else:                                   # F.pad(0,1,0,1) + stride-2 valid conv (autoencoder.py:476-478)
             Ho, Wo = (Hi + 1 - 3) // 2 + 1, (Wi + 1 - 3) // 2 + 1
-        g = TapGemm(A=A, W=W, M=nimg * Ho * Wo, N=W.shape[0], C1=C1, mode=L.TAP_CONV3X3, taps=9,
+        # r04: like the UNet's convs, a conv whose fp32 output feeds a GroupNorm leaves per-64-row-slab column statistics
+        # behind (vgen_tapgemm_args.colstats), so that norm skips its statistics pass: 10 -> 6 B / element on the 117 MB
+        # tensors of the 256 x 448 level.  Only where the launch is never split along K and the frame is whole slabs.
+        M = nimg * Ho * Wo
+        kw["colstats"] = bool(kw.get("colstats", False)) and M >= ops.COLSTATS_MIN_ROWS and (Ho * Wo) % ops.CS_ROWS == 0 \
+            and W.shape[0] % 4 == 0
+        g = TapGemm(A=A, W=W, M=M, N=W.shape[0], C1=C1, mode=L.TAP_CONV3X3, taps=9,
                     Hi=Hi, Wi=Wi, Ho=Ho, Wo=Wo, stride=stride, pad_t=pad, pad_l=pad, ups=ups, bias=b, **kw)
         return ops.backend().tapgemm(g), Ho, Wo
 
@@ -263,12 +320,12 @@ class AutoencoderKL(nn.Module):
         P = self._packed[m._pname]
         skip = m.cin != m.cout
         a1, raw = be.groupnorm(x, None, n, H * W, 32, 1e-6, *P["gn1"], True, skip, dt)
-        h, _, _ = self._conv(a1, P["conv1"], n, H, W, m.cin)
+        h, _, _ = self._conv(a1, P["conv1"], n, H, W, m.cin, colstats=True)
         a2, _ = be.groupnorm(h, None, n, H * W, 32, 1e-6, *P["gn2"], True, False, dt)
         if skip:
-            h, _, _ = self._conv(a2, P["conv2"], n, H, W, m.cout, A2=raw, C2=m.cin)
+            h, _, _ = self._conv(a2, P["conv2"], n, H, W, m.cout, A2=raw, C2=m.cin, colstats=True)
         else:
-            h, _, _ = self._conv(a2, P["conv2"], n, H, W, m.cout, residual=x)
+            h, _, _ = self._conv(a2, P["conv2"], n, H, W, m.cout, residual=x, colstats=True)
         return h
 
     def _attn(self, m: _AttnBlockP, x, n, H, W):
@@ -282,13 +339,23 @@ class AutoencoderKL(nn.Module):
         qk = be.tapgemm(TapGemm(A=a, W=Wqk, M=M, N=2 * c, C1=c, bias=bqk, out_dtype=dt))
         hwp = ((hw + 63) // 64) * 64
         o = torch.empty((M, c), dtype=dt, device=x.device)
+        scale = float(int(c) ** (-0.5))
+        if self._attn_fused and c == 512:
+            # V^T[i][c, p] = sum_ci Wv[c, ci] a[p, ci] per frame (pad columns stay zero), then ONE launch for the chunk
+            vt = torch.zeros((n, c, hwp), dtype=dt, device=x.device)
+            for i in range(n):
+                be.tapgemm(TapGemm(A=P["v"], W=a[i * hw:(i + 1) * hw], M=c, N=hw, C1=c, out_dtype=dt, out=vt[i]))
+            be.attention_d512(Attn(q=qk, k=qk[:, c:], v=vt, out=o, heads=1, nq=hw, nk=hw, nbatch=n, inner=1,
+                                   q_s=(2 * c, hw * 2 * c, 0), k_s=(2 * c, hw * 2 * c, 0), v_s=(hwp, c * hwp, 0),
+                                   o_s=(c, hw * c, 0), scale=scale))
+            Wo, _ = P["o"]
+            return be.tapgemm(TapGemm(A=o, W=Wo, M=M, N=c, C1=c, bias=P["ob_fused"], residual=x))
         # scores are formed per block of QB queries: S [QB, hw] fp32 stays <= 64 MiB (a whole 90x160 latent frame
         # of the 720p configs would need 829 MB for hw x hw; 32x56 frames fit in one block)
         QB = min(hw, self._attn_qb or max(256, ((16 << 20) // hwp) // 256 * 256))
         S = torch.empty((QB, hw), dtype=torch.float32, device=x.device)
         Pm = torch.zeros((QB, hwp), dtype=dt, device=x.device)          # pad columns stay zero
         vt = torch.zeros((c, hwp), dtype=dt, device=x.device)
-        scale = float(int(c) ** (-0.5))
         for i in range(n):
             rows = slice(i * hw, (i + 1) * hw)
             # V^T[c, p] = sum_ci Wv[c, ci] a[p, ci]  (bias folded after PV: softmax rows sum to 1)
@@ -316,7 +383,7 @@ class AutoencoderKL(nn.Module):
     # -- public API ----------------------------------------------------------------------------------
     @torch.no_grad()
     def decode(self, z, **kwargs):
-        o, n, H, W = self._decode_rows(z)
+        o, n, H, W = self._graphed("decode", self._decode_rows, z)
         be = ops.backend()
         oc = o.shape[1]
         out = torch.empty((n, oc, H, W), dtype=torch.float32, device=z.device)
@@ -329,7 +396,7 @@ class AutoencoderKL(nn.Module):
         """decode + the engines' post-processing (utils/video_op.py:181-188) in one pass: the decoder's rows
         are already (frame, y, x, channel)-ordered, so the byte image [n, H, W, 3] is written straight from
         them — no NCHW tensor, no fp32 D2H of 22 MB per video."""
-        o, n, H, W = self._decode_rows(z)
+        o, n, H, W = self._graphed("decode", self._decode_rows, z)
         key = (tuple(mean), tuple(std), o.device)
         if getattr(self, "_u8_consts", (None,))[0] != key:
             self._u8_consts = (key, torch.tensor(mean, dtype=torch.float32, device=o.device),
@@ -429,7 +496,7 @@ class AutoencoderKL(nn.Module):
                 h = self._resnet(blk, h, n, H, W)
             if i != 0:
                 a = be.act_cast(h, 0, dt)
-                h, H, W = self._conv(a, P[lvl.upsample._pname], n, H, W, h.shape[1], ups=1)
+                h, H, W = self._conv(a, P[lvl.upsample._pname], n, H, W, h.shape[1], ups=1, colstats=True)
         a, _ = be.groupnorm(h, None, n, H * W, 32, 1e-6, *P["decoder.norm_out"], True, False, dt)
         o, _, _ = self._conv(a, P["decoder.conv_out"], n, H, W, h.shape[1])
         return o, n, H, W
@@ -450,7 +517,7 @@ class AutoencoderKL(nn.Module):
                 h = self._resnet(blk, h, n, H, W)
             if i != enc.num_resolutions - 1:
                 a = be.act_cast(h, 0, dt)
-                h, H, W = self._conv(a, P[lvl.downsample._pname], n, H, W, h.shape[1], stride=2, pad=0)
+                h, H, W = self._conv(a, P[lvl.downsample._pname], n, H, W, h.shape[1], stride=2, pad=0, colstats=True)
         h = self._mid(enc.mid, h, n, H, W)
         a, _ = be.groupnorm(h, None, n, H * W, 32, 1e-6, *P["encoder.norm_out"], True, False, dt)
         m, _, _ = self._conv(a, P["encoder.conv_out"], n, H, W, h.shape[1])
@@ -463,8 +530,8 @@ class AutoencoderKL(nn.Module):
         return mom, n, H, W
 
     def encode(self, x):
-        mom, n, H, W = self._encode_rows(x)
-        return DiagonalGaussianDistribution(mom, n, self.zc, H, W)
+        mom, n, H, W = self._graphed("encode", self._encode_rows, x)
+        return DiagonalGaussianDistribution(mom.clone(), n, self.zc, H, W)     # the posterior outlives the next chunk
 
     def encode_firsr_stage(self, x, scale_factor=1.0):
         return self.encode(x).sample(scale_factor)
