@@ -23,7 +23,7 @@ import torch.nn as nn
 
 from . import lib as L
 from . import ops
-from .ops import TapGemm
+from .ops import Attn, TapGemm
 from .unet import _f32, _w16_cat, pack_conv3x3, pack_linear, pack_small_conv3x3, split_weights
 
 
