@@ -233,13 +233,6 @@ typedef struct vgen_attn_args {
 
 int vgen_attention(const vgen_attn_args* args, void* stream);
 
-/* ABI 5: AttnBlock.forward of the AutoencoderKL (tools/modules/autoencoder.py:418-442): ONE head of 512 channels,
- * softmax(q k^T * scale) v fused (scores and probabilities never leave the CU; r03: scores-GEMM -> fp32 S in HBM ->
- * vgen_softmax_rows -> PV-GEMM per frame and query block).  Same argument block; heads must be 1, head dim is 512,
- * `v` is V^T: [512][>= nk] per sequence with row stride v_rs >= nk rounded up to 32 (the host's V^T = Wv . a^T GEMM writes
- * it that way), q / k / out rows hold 512 elements at row strides q_rs / k_rs / o_rs. */
-int vgen_attention_d512(const vgen_attn_args* args, void* stream);
-
 /* Row softmax: P[r, :] = softmax(S[r, :] * scale), fp32 in -> 16-bit out.
  * Single-head 512-channel VAE attention, autoencoder.py:430-437 (bmm, scale, softmax). */
 int vgen_softmax_rows(const float* S, int64_t rows, int32_t cols, int64_t lds, float scale,

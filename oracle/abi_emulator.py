@@ -168,19 +168,6 @@ class EmuBackend:
             ov[a:a + step].copy_((torch.softmax(sc, dim=-1) @ v[a:a + step]).to(g.out.dtype))
         return g.out
 
-    def attention_d512(self, g):
-        # vgen_attention_d512: one head of 512 channels; v is V^T [nbatch, 512, >= nk]
-        assert g.heads == 1 and g.inner == 1
-        nb = g.nbatch
-        q = _strided(g.q, (nb, g.nq, 512), (g.q_s[1], g.q_s[0], 1)).float()
-        k = _strided(g.k, (nb, g.nk, 512), (g.k_s[1], g.k_s[0], 1)).float()
-        vt = _strided(g.v, (nb, 512, g.nk), (g.v_s[1], g.v_s[0], 1)).float()
-        ov = _strided(g.out, (nb, g.nq, 512), (g.o_s[1], g.o_s[0], 1))
-        for i in range(nb):
-            w = torch.softmax(q[i] @ k[i].t() * g.scale, dim=-1)
-            ov[i].copy_((w @ vt[i].t()).to(g.out.dtype))
-        return g.out
-
     def softmax_rows(self, S, cols, scale, dt, out=None):
         p = torch.softmax(S[:, :cols].float() * scale, dim=-1).to(dt)
         if out is None:

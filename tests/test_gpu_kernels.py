@@ -126,43 +126,6 @@ def test_attention(hip_backend, dtname, name):
 
 
 @pytest.mark.parametrize("dtname", ["bf16", "fp16"])
-@pytest.mark.parametrize("nb,hw,amp", [(2, 1792, 1.0), (1, 375, 1.0), (3, 97, 3.0), (1, 4000, 1.0)])
-def test_attention_d512(hip_backend, dtname, nb, hw, amp):
-    """vgen_attention_d512 (r04: the AutoencoderKL's mid attention, one head of 512 channels, V passed transposed) against
-    fp32 softmax(q k^T / sqrt(512)) v on the same 16-bit operands: a full frame (1792 = 56 tiles of 32 keys), ragged
-    query / key tails (375, 97: last tiles masked, V^T pad columns zero), peaky scores (amp 3: the running maximum keeps
-    growing -> the rescale path) and a long sequence; q / k interleaved in one [M, 1024] matrix like the host's qk GEMM.
-    The reference is not symmetric in (q, k) or (d, key): a transposed operand or output would be caught."""
-    from vgen_amd.ops import Attn
-    dt = kc.DTS[dtname]
-    g = torch.Generator().manual_seed(hw)
-    c = 512
-    qk = (torch.randn(nb * hw, 2 * c, generator=g) * amp * 0.5).to(dt)
-    v = torch.randn(nb, hw, c, generator=g).to(dt)
-    hwp = ((hw + 63) // 64) * 64
-    vt = torch.zeros(nb, c, hwp, dtype=dt)
-    vt[:, :, :hw] = v.transpose(1, 2)
-    scale = c ** -0.5
-    o = torch.full((nb * hw, c), float("nan"), dtype=dt, device=DEV)
-    qk_d, vt_d = qk.to(DEV), vt.to(DEV)
-    hip_backend.attention_d512(Attn(q=qk_d, k=qk_d[:, c:], v=vt_d, out=o, heads=1, nq=hw, nk=hw, nbatch=nb, inner=1,
-                                    q_s=(2 * c, hw * 2 * c, 0), k_s=(2 * c, hw * 2 * c, 0), v_s=(hwp, c * hwp, 0),
-                                    o_s=(c, hw * c, 0), scale=scale))
-    q32 = qk[:, :c].float().view(nb, hw, c)
-    k32 = qk[:, c:].float().view(nb, hw, c)
-    ref = torch.softmax(q32 @ k32.transpose(1, 2) * scale, -1) @ v.float()
-    got = o.float().cpu().view(nb, hw, c)
-    assert torch.isfinite(got).all()
-    err = float((got - ref).norm() / ref.norm())
-    assert err <= 3 * kc.TOL16[dtname], err          # P is rounded to 16 bit before the PV product, like flash_kernel
-    o2 = torch.empty_like(o)
-    hip_backend.attention_d512(Attn(q=qk_d, k=qk_d[:, c:], v=vt_d, out=o2, heads=1, nq=hw, nk=hw, nbatch=nb, inner=1,
-                                    q_s=(2 * c, hw * 2 * c, 0), k_s=(2 * c, hw * 2 * c, 0), v_s=(hwp, c * hwp, 0),
-                                    o_s=(c, hw * c, 0), scale=scale))
-    assert torch.equal(o, o2)
-
-
-@pytest.mark.parametrize("dtname", ["bf16", "fp16"])
 def test_softmax_rows(hip_backend, dtname):
     res = kc.case_softmax_rows(hip_backend, DEV, kc.DTS[dtname], 70, 200, 256)
     assert res["P"]["pad_untouched"]

@@ -510,21 +510,3 @@ def test_vae_attention_query_blocks(emu_backend):
     with pytest.raises(NotImplementedError):
         AutoencoderKL(ddconfig=g["ddconfig"], embed_dim=8)
 
-
-def test_vae_fused_mid_attention_host_logic(emu_backend):
-    """r04: the 512-channel mid attention through vgen_attention_d512 (q | k interleaved in one matrix, V^T per frame,
-    value bias folded into the output projection) against the per-frame GEMM path — host logic on the emulator; a model
-    whose mid block really has 512 channels (the tiny fixtures have 256 and never reach the fused path)."""
-    from vgen_amd.vae import AutoencoderKL
-    dd = dict(double_z=True, z_channels=4, resolution=32, in_channels=3, out_ch=3, ch=128, ch_mult=[1, 4], num_res_blocks=1,
-              attn_resolutions=[], dropout=0.0)
-    v = AutoencoderKL(ddconfig=dd, embed_dim=4, compute_dtype="fp16").eval()
-    shapes = {k: tuple(p.shape) for k, p in v.state_dict().items()}
-    v.load_state_dict(torch_ref.synth_state_dict(shapes, seed=7), strict=True)
-    assert v.decoder.mid.attn_1.c == 512 and v._attn_fused
-    z = torch.randn(2, 4, 5, 6, generator=torch.Generator().manual_seed(1))
-    fused = v.decode(z)
-    v._attn_fused = False
-    legacy = v.decode(z)
-    assert fused.shape == (2, 3, 10, 12) and torch.isfinite(fused).all()
-    assert rel_l2(fused, legacy) < 1e-3

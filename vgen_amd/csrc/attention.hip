@@ -266,198 +266,6 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(const vgen_attn_args p, i
 
 
 // =========================================================================================
-// flash512_kernel (r04): the AutoencoderKL's mid attention (autoencoder.py:418-442) — ONE head of 512 channels over the
-// hw pixels of a frame (1 792 at 256x448, 14 400 at 720p).  r03 ran it per frame and query block as scores-GEMM ->
-// fp32 S in HBM (829 MB per 720p frame) -> row softmax -> PV-GEMM; here S and P never leave the CU.
-//   Block = 4 waves = 64 queries, KV tiles of 32 keys, double-buffered in LDS (K rows padded to 1040 B, V^T rows to
-//   80 B: conflict-free fragment reads).  V arrives TRANSPOSED from the host's V^T = Wv . a^T GEMM, so no kernel has to
-//   transpose anything.
-//   Two phases per tile, both on all 4 waves:
-//     S  : wave w owns queries 16w .. 16w+15: S^T[32 keys][16 q] over d = 512 (32 MFMAs, Q fragments resident in 64
-//          VGPRs), online softmax in-lane + 2 shuffles, P^T as the ready-made B operand of the PV product -> LDS
-//          (4 KB), per-query rescale factors -> LDS;
-//     PV : wave w owns the output channels 128w .. 128w+127 of ALL 64 queries: O^T[128 d][64 q] (128 accumulator
-//          VGPRs) += V^T-frag . P^T-frag (32 MFMAs); the rescale by alpha is skipped when no query of the block saw a new
-//          maximum (block-uniform flag: after the first tiles that is almost always).
-//   A 512-wide O row does not fit one wave's registers next to its Q row — hence the d-split of the PV phase.
-template <typename T>
-__global__ __launch_bounds__(256, 1) void flash512_kernel(const vgen_attn_args p, int qtiles) {
-  constexpr int D = 512, BQ = 64, BKV = 32;
-  constexpr int KS = 1040;                 // K row stride in bytes (1024 + 16: rows shift by 4 banks)
-  constexpr int VS = 40;                   // V^T row stride in elements (32 keys + 8 pad = 80 B)
-  extern __shared__ __attribute__((aligned(16))) unsigned char sm512[];
-  unsigned char* const sK = sm512;                                   // [2][BKV * KS]
-  uint16_t* const sVt = (uint16_t*)(sm512 + 2 * BKV * KS);           // [2][D * VS]
-  u32x4* const sP = (u32x4*)(sm512 + 2 * BKV * KS + 2 * D * VS * 2); // [4 waves][64 lanes]
-  float* const sA = (float*)(sP + 256);                              // [64] alpha, [64] 1/l (epilogue), [4] grew flags
-  int* const sF = (int*)(sA + 128);
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int lr = lane & 15, lq = lane >> 4;
-  int64_t bid = blockIdx.x;
-  const int qt = (int)(bid % qtiles);
-  const int64_t bi = bid / qtiles;
-  const uint16_t* Q = (const uint16_t*)p.q + seq_off(bi, p.inner, p.q_bo, p.q_bi);
-  const uint16_t* K = (const uint16_t*)p.k + seq_off(bi, p.inner, p.k_bo, p.k_bi);
-  const uint16_t* Vt = (const uint16_t*)p.v + seq_off(bi, p.inner, p.v_bo, p.v_bi);   // [512][>= nk], row stride v_rs
-  uint16_t* O = (uint16_t*)p.out + seq_off(bi, p.inner, p.o_bo, p.o_bi);
-  const int q0 = qt * BQ;
-
-  // Q fragments of this wave's 16 queries (B operand): lane (lq, lr): Q[q0 + 16 wave + lr][32 ks + 8 lq .. +8]
-  u32x4 qf[16];
-  {
-    const int row = q0 + wave * 16 + lr;
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (row < p.nq) v = *(const u32x4*)(Q + (int64_t)row * p.q_rs + ks * 32 + lq * 8);
-      qf[ks] = v;
-    }
-  }
-  f32x4 o_acc[8][4];
-#pragma unroll
-  for (int df = 0; df < 8; ++df)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) o_acc[df][j] = f32x4{0, 0, 0, 0};
-  float m_run = -INFINITY, l_run = 0.f;
-  const float c = p.scale * 1.44269504088896340736f;
-
-  // staging: K tile = 32 rows x 1 KiB: thread -> row tid >> 3, 8 chunks of 16 B at (tid & 7) + 8 i;
-  //          V^T tile = 512 rows x 64 B: thread -> rows tid + 256 i (i < 2), 4 chunks of 16 B each
-  const int k_row = tid >> 3, k_c0 = tid & 7;
-  u32x4 rk[8], rv[8];
-  auto gload = [&](int kv0) {
-    const bool kok = kv0 + k_row < p.nk;
-    const uint16_t* ksrc = K + (int64_t)(kv0 + k_row) * p.k_rs;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) rk[i] = kok ? *(const u32x4*)(ksrc + (k_c0 + 8 * i) * 8) : u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const uint16_t* vsrc = Vt + (int64_t)(tid + 256 * i) * p.v_rs + kv0;
-#pragma unroll
-      for (int ch = 0; ch < 4; ++ch) {
-        // the host pads V^T rows to a multiple of 64 keys with zeros (pad columns of P are masked anyway)
-        rv[i * 4 + ch] = (kv0 + ch * 8 < p.nk) ? *(const u32x4*)(vsrc + ch * 8) : u32x4{0u, 0u, 0u, 0u};
-      }
-    }
-  };
-  auto lstore = [&](int buf) {
-    unsigned char* kd = sK + buf * (BKV * KS) + k_row * KS;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) *(u32x4*)(kd + (k_c0 + 8 * i) * 16) = rk[i];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      uint16_t* vd = sVt + buf * (D * VS) + (tid + 256 * i) * VS;
-#pragma unroll
-      for (int ch = 0; ch < 4; ++ch) *(u32x4*)(vd + ch * 8) = rv[i * 4 + ch];
-    }
-  };
-
-  const int ntile = (p.nk + BKV - 1) / BKV;
-  gload(0);
-  lstore(0);
-  __syncthreads();
-  for (int t = 0; t < ntile; ++t) {
-    const int kv0 = t * BKV, buf = t & 1;
-    const bool more = t + 1 < ntile;
-    if (more) gload(kv0 + BKV);
-    const unsigned char* cK = sK + buf * (BKV * KS);
-    const uint16_t* cV = sVt + buf * (D * VS);
-
-    // ---- S phase: S^T[32 keys][16 q of this wave] ------------------------------------------------------------
-    f32x4 s[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
-#pragma unroll
-    for (int ks = 0; ks < 16; ++ks) {
-#pragma unroll
-      for (int kf = 0; kf < 2; ++kf) {
-        const u32x4 kfrag = *(const u32x4*)(cK + (kf * 16 + lr) * KS + (ks * 4 + lq) * 16);
-        s[kf] = T::mfma32(kfrag, qf[ks], s[kf]);
-      }
-    }
-    if (kv0 + BKV > p.nk) {
-#pragma unroll
-      for (int kf = 0; kf < 2; ++kf)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s[kf][r] = (kv0 + kf * 16 + lq * 4 + r < p.nk) ? s[kf][r] : -INFINITY;
-    }
-    float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    const bool grew = __builtin_amdgcn_ballot_w64(m_new > m_run) != 0ull;
-    const float mc = m_new * c;
-    float pv[2][4], psum = 0.f;
-#pragma unroll
-    for (int kf = 0; kf < 2; ++kf)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        pv[kf][r] = fast_exp2(s[kf][r] * c - mc);
-        psum += pv[kf][r];
-      }
-    float alpha = 1.0f;
-    if (grew) alpha = fast_exp2((m_run - m_new) * c);      // m_run = -inf on the first tile: exp2(-inf) = 0
-    m_run = m_new;
-    l_run = l_run * alpha + psum;
-    {
-      // B operand of the PV product for this wave's queries: virtual k = 8 lq + e <-> key 4 lq + e (e < 4), 16 + 4 lq + e - 4
-      u32x4 tt;
-      tt.x = pack2<T>(pv[0][0], pv[0][1]);
-      tt.y = pack2<T>(pv[0][2], pv[0][3]);
-      tt.z = pack2<T>(pv[1][0], pv[1][1]);
-      tt.w = pack2<T>(pv[1][2], pv[1][3]);
-      sP[wave * 64 + lane] = tt;
-      if (lq == 0) sA[wave * 16 + lr] = alpha;
-      if (lane == 0) sF[wave] = grew ? 1 : 0;
-    }
-    __syncthreads();
-
-    // ---- PV phase: O^T[d = 128 wave + 16 df + ..][64 q] += V^T P^T ------------------------------------------------
-    if (sF[0] | sF[1] | sF[2] | sF[3]) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float a = sA[j * 16 + lr];
-#pragma unroll
-        for (int df = 0; df < 8; ++df) o_acc[df][j] *= a;
-      }
-    }
-    u32x4 pb[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) pb[j] = sP[j * 64 + lane];
-#pragma unroll
-    for (int df = 0; df < 8; ++df) {
-      const uint16_t* vr = cV + (wave * 128 + df * 16 + lr) * VS + lq * 4;
-      const u32x2 lo = *(const u32x2*)vr;
-      const u32x2 hi = *(const u32x2*)(vr + 16);
-      const u32x4 vfrag = {lo.x, lo.y, hi.x, hi.y};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o_acc[df][j] = T::mfma32(vfrag, pb[j], o_acc[df][j]);
-    }
-    if (more) lstore(buf ^ 1);
-    __syncthreads();
-  }
-
-  // ---- normalise and store: PV wave `wave` owns O[q][128 wave + 16 df + 4 lq + r] for all 64 queries --------------
-  {
-    float l = l_run;
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
-    if (lq == 0) sA[64 + wave * 16 + lr] = 1.0f / l;
-  }
-  __syncthreads();
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int row = q0 + j * 16 + lr;
-    if (row >= p.nq) continue;
-    const float inv = sA[64 + j * 16 + lr];
-#pragma unroll
-    for (int df = 0; df < 8; ++df) {
-      const f32x4 o = o_acc[df][j] * inv;
-      *(u32x2*)(O + (int64_t)row * p.o_rs + wave * 128 + df * 16 + lq * 4) = pack4<T>(o.x, o.y, o.z, o.w);
-    }
-  }
-}
-
-// =========================================================================================
 // History: r01 saw this kernel drift from run to run under `__launch_bounds__(256, 2)` and kept the default bounds
 // without a cause.  Root cause (r02, tools/determinism_probe.py located the first differing launch, the ISA showed
 // it): BF16::pack2 was an inline-asm `v_cvt_pk_bf16_f32`; with min-2-blocks bounds the MFMA results stay in VGPRs
@@ -595,47 +403,14 @@ extern "C" int vgen_attention(const vgen_attn_args* args, void* stream) {
   return vgen_check_launch("attention(flash)");
 }
 
-// One head of 512 channels (the AutoencoderKL's mid attention): q, k rows of 512 elements (row strides q_rs / k_rs),
-// v = V^T [512][>= nk] per sequence (row stride v_rs; columns beyond nk up to the next multiple of 32 must be readable),
-// out rows of 512.  heads must be 1.
-extern "C" int vgen_attention_d512(const vgen_attn_args* args, void* stream) {
-  if (!args) {
-    vgen_set_error("attention_d512: null args");
-    return VGEN_E_BADARG;
-  }
-  const vgen_attn_args& a = *args;
-  VGEN_REQUIRE(a.dtype == VGEN_BF16 || a.dtype == VGEN_F16, "attention_d512: dtype");
-  VGEN_REQUIRE(a.heads == 1 && a.nq > 0 && a.nk > 0 && a.nbatch > 0 && a.inner > 0 && a.causal == 0,
-               "attention_d512: one head, no mask");
-  VGEN_REQUIRE(vgen_aligned16(a.q) && vgen_aligned16(a.k) && vgen_aligned16(a.v) && vgen_aligned16(a.out),
-               "attention_d512: pointer alignment");
-  VGEN_REQUIRE((a.q_rs | a.q_bo | a.q_bi | a.k_rs | a.k_bo | a.k_bi | a.v_rs | a.v_bo | a.v_bi | a.o_rs | a.o_bo | a.o_bi) % 8 == 0,
-               "attention_d512: strides must be multiples of 8 elements");
-  VGEN_REQUIRE(a.v_rs >= ((int64_t)(a.nk + 31) / 32) * 32, "attention_d512: V^T rows must be padded to a multiple of 32 keys");
-  constexpr int LDS = 2 * 32 * 1040 + 2 * 512 * 40 * 2 + 256 * 16 + 128 * 4 + 16;
-  static bool attr_done = false;
-  if (!attr_done) {
-    hipError_t e1 = hipFuncSetAttribute((const void*)flash512_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    hipError_t e2 = hipFuncSetAttribute((const void*)flash512_kernel<F16>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-    if (e1 != hipSuccess || e2 != hipSuccess) {
-      vgen_set_error("attention_d512: hipFuncSetAttribute(LDS) failed");
-      return VGEN_E_BADARG;
-    }
-    attr_done = true;
-  }
-  const int qtiles = (a.nq + 63) / 64;
-  const int64_t grid = a.nbatch * qtiles;
-  VGEN_REQUIRE(grid < (1LL << 31), "attention_d512: grid too large");
-  hipStream_t s = (hipStream_t)stream;
-  if (a.dtype == VGEN_BF16)
-    hipLaunchKernelGGL(flash512_kernel<BF16>, dim3((unsigned)grid), dim3(256), LDS, s, a, qtiles);
-  else
-    hipLaunchKernelGGL(flash512_kernel<F16>, dim3((unsigned)grid), dim3(256), LDS, s, a, qtiles);
-  return vgen_check_launch("attention_d512");
-}
-
 // =========================================================================================
 // Row softmax for the VAE's single-head 512-channel attention (scores via tap-GEMM).
+// r04: a fused flash kernel for that attention (one head of 512 channels, V^T operand, O accumulators split over the waves
+// by channel: vgen_attention_d512, commit d51c7ab) was built, passed its parity cases and measured 57 TFLOP/s — 0.23 ms for
+// two 1 792-token frames against ~0.11 ms for this scores-GEMM -> softmax -> PV-GEMM sequence
+// (profiles/r04c_vae_shapes_256x448_high_fused_attention.json): a 512-wide output row leaves room for only 64 queries per
+// block, so every block re-stages the whole K / V^T stream (64 KB per 32 keys) for 8 MFLOP of work and is bound by the
+// load issue, not by the matrix pipe.  The GEMM formulation tiles the same products 256 x 128; the kernel was removed again.
 namespace {
 template <typename T>
 __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* __restrict__ S,

@@ -71,7 +71,6 @@ SYMBOLS = {
     "vgen_tapgemm_query_plan": (C.c_int, [C.POINTER(TapGemmArgs), _vp]),
     "vgen_tapgemm_set_plans": (C.c_int, [_vp, _i32]),
     "vgen_attention": (C.c_int, [C.POINTER(AttnArgs), _vp]),
-    "vgen_attention_d512": (C.c_int, [C.POINTER(AttnArgs), _vp]),
     "vgen_softmax_rows": (C.c_int, [_vp, _i64, _i32, _i64, _f32, _vp, _i64, _i32, _vp]),
     "vgen_act_cast": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
     "vgen_cast_split": (C.c_int, [_vp, _i64, _i32, _i64, _vp, _i64, _i32, _i32, _vp]),

@@ -307,24 +307,6 @@ class HipBackend:
         _lib.check(rc, "vgen_attention")
         return g.out
 
-    def attention_d512(self, g: Attn):
-        """vgen_attention_d512: one head of 512 channels, v = V^T [nbatch, 512, >= nk] (the AutoencoderKL's mid attention)."""
-        assert g.heads == 1 and not g.causal
-        a = _lib.AttnArgs()
-        a.q, a.k, a.v, a.out = g.q.data_ptr(), g.k.data_ptr(), g.v.data_ptr(), g.out.data_ptr()
-        a.dtype, a.heads, a.nq, a.nk = _ENUM[g.q.dtype], 1, g.nq, g.nk
-        a.nbatch, a.inner = g.nbatch, g.inner
-        a.q_rs, a.q_bo, a.q_bi = g.q_s
-        a.k_rs, a.k_bo, a.k_bi = g.k_s
-        a.v_rs, a.v_bo, a.v_bi = g.v_s
-        a.o_rs, a.o_bo, a.o_bi = g.o_s
-        a.scale = float(g.scale)
-        a.causal = 0
-        with self._Prof("attention_d512", 4.0 * g.nbatch * g.nq * g.nk * 512, (g.nbatch, 1, g.nq, g.nk)):
-            rc = self.lib.vgen_attention_d512(C.byref(a), self._stream(g.q))
-        _lib.check(rc, "vgen_attention_d512")
-        return g.out
-
     def softmax_rows(self, S, cols, scale, dt, out=None):
         S = _mat(S, "S")
         rows = S.shape[0]

@@ -13,7 +13,6 @@ scores-GEMM -> row softmax kernel -> PV-GEMM.
 """
 from __future__ import annotations
 
-import os
 
 import collections
 import logging
@@ -23,7 +22,7 @@ import torch.nn as nn
 
 from . import lib as L
 from . import ops
-from .ops import Attn, TapGemm
+from .ops import TapGemm
 from .unet import _f32, _w16_cat, pack_conv3x3, pack_linear, pack_small_conv3x3, split_weights
 
 
@@ -177,10 +176,7 @@ class AutoencoderKL(nn.Module):
         self.precision = precision or "fast"      # "high": weights as hi + lo operand pairs (vgen_amd/unet.py)
         assert self.precision in ("fast", "high")
         self._packed = None
-        self._attn_qb = None          # query-block override of the legacy (GEMM) mid attention (tests force several blocks)
-        # r04: the mid attention as ONE fused launch over all frames of a chunk (vgen_attention_d512); False = the r03
-        # sequence per frame and query block (scores GEMM -> fp32 S -> row softmax -> PV GEMM), kept as a cross-check
-        self._attn_fused = os.environ.get("VGEN_VAE_ATTN_FUSED", "1") != "0"
+        self._attn_qb = None          # query-block override of the mid attention (tests force several blocks)
         self._graphs = {}             # (kind, input shape, device) -> captured launch sequence of a decode / encode chunk
         if pretrained is not None:
             self.init_from_ckpt(pretrained, ignore_keys=ignore_keys)
@@ -207,7 +203,7 @@ class AutoencoderKL(nn.Module):
         self._graphs = {}
 
     # -- r04: a decode / encode chunk is ONE hipGraph replay ------------------------------------------------------
-    _GRAPH_SHAPES = 2             # captured input shapes kept per model (each holds a chunk's peak activations)
+    _GRAPH_SHAPES = 4             # captured input shapes kept per model (each holds a chunk's peak activations)
 
     def _graphed(self, kind, rows_fn, x):
         """rows_fn(x) -> (rows, n, H, W) through a captured graph keyed on (kind, x.shape): the engines decode a video as
@@ -219,7 +215,7 @@ class AutoencoderKL(nn.Module):
         from .session import _GRAPH_ON
         if not _GRAPH_ON or x.device.type != "cuda":
             return rows_fn(x)
-        key = (kind, tuple(x.shape), str(x.device), self._attn_qb, self._attn_fused)
+        key = (kind, tuple(x.shape), str(x.device), self._attn_qb)
         st = self._graphs.get(key)
         if st is None:
             while len(self._graphs) >= self._GRAPH_SHAPES:
@@ -276,10 +272,7 @@ class AutoencoderKL(nn.Module):
                     "qk": (pack_linear(torch.cat([m.q.weight, m.k.weight], 0), dt),
                            torch.cat([_f32(m.q.bias), _f32(m.k.bias)]).contiguous()),
                     "v": pack_linear(m.v.weight, dt), "vb": _f32(m.v.bias),
-                    "o": (pack_linear(m.proj_out.weight, dt), _f32(m.proj_out.bias)),
-                    # fused attention: softmax rows sum to 1, so the value bias passes through the attention unchanged
-                    # and is folded (fp32) into the output projection's bias: Wo (P V + 1 vb^T) + bo = Wo P V + (Wo vb + bo)
-                    "ob_fused": (_f32(m.proj_out.bias) + _f32(m.proj_out.weight).reshape(m.c, m.c) @ _f32(m.v.bias)).contiguous()}
+                    "o": (pack_linear(m.proj_out.weight, dt), _f32(m.proj_out.bias))}
             elif isinstance(m, _ResampleP):
                 P[name] = (pack_conv3x3(m.conv.weight, dt), _f32(m.conv.bias))
         for side in ("encoder", "decoder"):
@@ -340,16 +333,6 @@ class AutoencoderKL(nn.Module):
         hwp = ((hw + 63) // 64) * 64
         o = torch.empty((M, c), dtype=dt, device=x.device)
         scale = float(int(c) ** (-0.5))
-        if self._attn_fused and c == 512:
-            # V^T[i][c, p] = sum_ci Wv[c, ci] a[p, ci] per frame (pad columns stay zero), then ONE launch for the chunk
-            vt = torch.zeros((n, c, hwp), dtype=dt, device=x.device)
-            for i in range(n):
-                be.tapgemm(TapGemm(A=P["v"], W=a[i * hw:(i + 1) * hw], M=c, N=hw, C1=c, out_dtype=dt, out=vt[i]))
-            be.attention_d512(Attn(q=qk, k=qk[:, c:], v=vt, out=o, heads=1, nq=hw, nk=hw, nbatch=n, inner=1,
-                                   q_s=(2 * c, hw * 2 * c, 0), k_s=(2 * c, hw * 2 * c, 0), v_s=(hwp, c * hwp, 0),
-                                   o_s=(c, hw * c, 0), scale=scale))
-            Wo, _ = P["o"]
-            return be.tapgemm(TapGemm(A=o, W=Wo, M=M, N=c, C1=c, bias=P["ob_fused"], residual=x))
         # scores are formed per block of QB queries: S [QB, hw] fp32 stays <= 64 MiB (a whole 90x160 latent frame
         # of the 720p configs would need 829 MB for hw x hw; 32x56 frames fit in one block)
         QB = min(hw, self._attn_qb or max(256, ((16 << 20) // hwp) // 256 * 256))
