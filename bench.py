@@ -460,6 +460,16 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
+    elif args.partition and os.environ.get("VGEN_FORCE_COLLECTIVE") == "1":
+        # one rank, collectives forced: the partition path's RCCL all-gather really executes on a 1-GPU box (a functional /
+        # overhead measurement of the multi-GPU step path, not a scaling number)
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(port))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
 
     ops.set_backend(None)
     assert ops.backend().name == "hip"
@@ -562,7 +572,9 @@ def main():
                    f"unit partition over {world} ranks, 1 all-gather/step ({args.backend}{', all ranks on one device: functional test' if one_dev else ''})"
                    + (", collective inside the step graph" if (part is not None and part.graph_collective) else ""),
                    "hipgraph": bool(sess is not None and sess.use_graph and sess._graphs) and
-                   ("whole step" if (part is None and args.config != "sr600") else "units' forward"),
+                   ("whole step" if (part is None and args.config != "sr600") else
+                    ("whole partitioned step (forward + all-gather + update)" if (part is not None and part.graph_collective)
+                     else "units' forward")),
                    "precision": args.precision,
                    "two_term_weight_levels": getattr(model, "MIXED_LEVELS", None) if getattr(model, "precision", "") == "mixed" else
                    ("all" if getattr(model, "precision", "") == "high" else "none"),
@@ -701,7 +713,7 @@ def main():
                            "measured_in_this_run": True}
         # HBM-side bytes per launch cannot be read from inside the process: they come from committed rocprofv3 PMC
         # passes of this command (tools/collect_evidence.sh -> profiles/) and are labelled as such
-        for tname in ("r03_tapgemm_traffic.json", "r02_tapgemm_traffic.json"):
+        for tname in ("r04_tapgemm_traffic.json", "r03_tapgemm_traffic.json", "r02_tapgemm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
@@ -914,6 +926,7 @@ def main():
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()                      # rank 0 ran the untimed extras (roofline pass, VAE); leave together
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -1,15 +1,33 @@
 #!/bin/bash
-# Run on the GPU box (via gpurun) from the repo root: bench line + rocprofv3 kernel stats + PMC counters (separate
-# passes, --pmc only: never combined with tracing).  Outputs under gpurun_out/evidence/; copy what should be judged
-# into profiles/.
+# Run on the GPU box (via gpurun) from the repo root: the whole -m gpu suite, the default bench line, rocprofv3 kernel stats
+# of the same step (eager launches, csv) and the PMC counters in SEPARATE --pmc-only passes (never combined with tracing),
+# the multi-GPU step path on one device (eager gather / update vs the captured step with the RCCL all-gather inside).
+# Outputs under gpurun_out/evidence/; tools/evidence_to_profiles.py <tag> turns them into the profiles/<tag>_* files.
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/evidence
 mkdir -p $O
+cd $R
+timeout 1200 python -m pytest tests -q -m gpu -p no:cacheprovider --maxfail=8 > $O/pytest_gpu.log 2>&1; tail -4 $O/pytest_gpu.log
+cp gpurun_out/parity.json $O/parity.json 2>/dev/null
+timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -4 $O/smoke.log
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --no-graph --no-cpu-baseline --no-vae --no-roofline --no-e2e"
-timeout 300 python $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+PREC=${PREC:-mixed}
+B="python $R/bench.py --precision $PREC --no-graph --no-cpu-baseline --no-vae --no-roofline --no-e2e --no-parity --no-scaling-model --variants="
+timeout 600 python $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
 tail -c 1500 $O/bench.json
+P="--steps 20 --warmup 5 --no-cpu-baseline --no-vae --no-roofline --no-e2e --no-parity --no-scaling-model --variants= --partition"
+timeout 200 python $R/bench.py $P > $O/bench_partition_eager.json 2> $O/bench_partition_eager.err
+VGEN_FORCE_COLLECTIVE=1 timeout 200 python $R/bench.py $P > $O/bench_partition_eager_rccl.json 2> $O/bench_partition_eager_rccl.err
+VGEN_FORCE_COLLECTIVE=1 timeout 200 python $R/bench.py $P --graph-collective > $O/bench_partition_graph_rccl.json 2> $O/bench_partition_graph_rccl.err
+python - <<PY
+import json
+for f in ("bench_partition_eager", "bench_partition_eager_rccl", "bench_partition_graph_rccl"):
+    try:
+        d = json.loads(open("$O/%s.json" % f).read().strip().splitlines()[-1]); print(f, d["value"], d["ms_per_step"], d["config"]["hipgraph"])
+    except Exception as e:
+        print(f, "FAILED", e)
+PY
 rm -rf /tmp/prof_kt
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- $B --steps 5 --warmup 2 > $O/prof_bench.json 2> /dev/null
 python $R/tools/rocprof_summary.py $(ls /tmp/prof_kt/*/*kernel_stats.csv | head -1) $O/kernel_stats_summary.csv | head -24
@@ -21,5 +39,5 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI
   f=$(ls /tmp/prof_$tag/*/*counter_collection.csv 2>/dev/null | head -1)
   if [ -n "$f" ]; then SPECS="$SPECS $tag=$f"; else echo "no counter file for $c"; fi
 done
-python $R/tools/pmc_classes.py $O/pmc_classes.json $SPECS | head -80
+python $R/tools/pmc_classes.py $O/pmc_classes.json $SPECS | head -40
 echo EVIDENCE_DONE

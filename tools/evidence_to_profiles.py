@@ -1,4 +1,4 @@
-"""gpurun_out/evidence/* (tools/collect_evidence_r03.sh) -> profiles/<tag>_{bench_evidence.json, kernel_stats_summary.csv,
+"""gpurun_out/evidence/* (tools/collect_evidence.sh) -> profiles/<tag>_{bench_evidence.json, kernel_stats_summary.csv,
 pmc_classes.json, tapgemm_traffic.json}.  The traffic file is what bench.py quotes under roofline.committed.
 
     python tools/evidence_to_profiles.py r03 [precision] [dtype]
@@ -26,7 +26,7 @@ write = t["WRITE_SIZE_per_launch"] * 1024.0
 busy = t["SQ_VALU_MFMA_BUSY_CYCLES_total"] / (t["GRBM_GUI_ACTIVE_total"] * 32.0 * 4.0)
 out = {"source": "rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE | "
                  "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY) on `bench.py --steps 1 --warmup 1 --no-graph` "
-                 f"({dtype}, {prec}, t2v), tools/collect_evidence_r03.sh + tools/pmc_classes.py; FETCH_SIZE doubled (gfx950 "
+                 f"({dtype}, {prec}, t2v), tools/collect_evidence.sh + tools/pmc_classes.py; FETCH_SIZE doubled (gfx950 "
                  "tallies 128-B requests at 64 B), KB -> bytes x1024",
        "precision": prec, "dtype": dtype, "launches": t["launches"], "fetch_bytes_per_launch": fetch,
        "write_bytes_per_launch": write, "hbm_bytes_per_launch": fetch + write,
@@ -34,3 +34,9 @@ out = {"source": "rocprofv3 --pmc, separate passes (FETCH_SIZE | WRITE_SIZE | SQ
        "mfma_busy_frac": round(busy, 4)}
 json.dump(out, open(os.path.join(P, f"{tag}_tapgemm_traffic.json"), "w"), indent=1)
 print(json.dumps(out, indent=1))
+for f, dst in (("pytest_gpu.log", "pytest_gpu.log"), ("smoke.log", "smoke.log"), ("parity.json", "parity.json"),
+               ("bench_partition_eager.json", "bench_partition_eager.json"),
+               ("bench_partition_eager_rccl.json", "bench_partition_eager_rccl.json"),
+               ("bench_partition_graph_rccl.json", "bench_partition_graph_rccl.json")):
+    if os.path.exists(os.path.join(E, f)):
+        shutil.copy(os.path.join(E, f), os.path.join(P, f"{tag}_{dst}"))
