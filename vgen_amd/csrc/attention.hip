@@ -13,8 +13,8 @@
 //                       the rescale factor is one scalar per lane, and the C/D layout of S^T
 //                       (4 consecutive keys per lane) IS the B-operand layout of the PV product
 //                       (any k-permutation is legal as long as A and B agree), so P never
-//                       leaves registers.  V is written to LDS transposed ([d][key]) so the
-//                       matching A fragments are two ds_read_b64 each.
+//                       leaves registers.  V sits in LDS row-major like K; the matching A fragments
+//                       (V^T) are two ds_read_b64_tr_b16 each (gfx950's transpose read, r04).
 //
 //  temporal_kernel : nq, nk <= 16 (attention over the 16 frames of one pixel; batch = B*H*W,
 //                    up to 8960 sequences x heads).  One wave per (sequence, head): Q/K
@@ -28,6 +28,20 @@ namespace {
 
 constexpr int HD = 64;  // head dim
 
+// gfx950's LDS transpose read (ds_read_b64_tr_b16), semantics measured with tools/probes/tr16_probe.hip
+// (profiles/r04_tr16_probe.txt): inside every 16-lane group, source lane s = 4 j + q hands in the address of 4 consecutive
+// 16-bit elements = row j, columns 4 q .. 4 q + 3 of a [4][16] block; destination lane c = 4 q + e receives column c of that
+// block, rows 0 .. 3, in its 4 halves.  For V stored ROW-MAJOR [key][d] that is exactly the A fragment of the O^T = V^T P^T
+// product (lane -> one d, 4 consecutive keys): the transposition r03 did with DPP moves in the staging pass (8 x ~5 VALU per
+// thread and tile in a VALU-bound kernel) is free here.
+typedef short v4i16_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ u32x2 lds_read_tr16(const uint16_t* p) {
+  const v4i16_t r = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) v4i16_t*)p);
+  u32x2 o;
+  __builtin_memcpy(&o, &r, 8);
+  return o;
+}
+
 __device__ __forceinline__ int64_t seq_off(int64_t bi, int64_t inner, int64_t bo, int64_t bin) {
   return (bi / inner) * bo + (bi % inner) * bin;
 }
@@ -36,12 +50,13 @@ __device__ __forceinline__ int64_t seq_off(int64_t bi, int64_t inner, int64_t bo
 template <typename T>
 __global__ __launch_bounds__(256, 2) void flash_kernel(const vgen_attn_args p, int qtiles) {
   constexpr int BQ = 128, BKV = 64;
-  constexpr int VS = 72;  // V^T row stride in elements (64 keys + 8 pad) -> 144 B
-  // double-buffered K / V^T tiles: the global loads of tile t+1 are issued before the MFMAs of
+  constexpr int VS = 80;  // V row stride in elements (64 d + 16 pad) -> 160 B: the 8 rows x 32 B a half-wave's transpose
+                          // read touches then cover all 64 banks exactly once (row offsets 0, 40, 16, 56, 32, 8, 48, 24 words)
+  // double-buffered K / V tiles: the global loads of tile t+1 are issued before the MFMAs of
   // tile t and written to the other buffer after them -> one barrier per tile, HBM/L2 latency
   // hidden behind the compute (v1 was single-buffered with two barriers: latency-bound, 250 TF/s).
   __shared__ __attribute__((aligned(16))) unsigned char sK[2][BKV * 128];   // [key][64 d] swizzled
-  __shared__ __attribute__((aligned(16))) uint16_t sVt[2][HD * VS];         // [d][key]
+  __shared__ __attribute__((aligned(16))) uint16_t sV[2][BKV * VS];         // [key][d] row-major (r04: was [d][key])
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 15, lq = lane >> 4;
@@ -104,19 +119,10 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(const vgen_attn_args p, i
     unsigned char* dst = sK[buf] + k_row * 128;
     *(u32x4*)(dst + (((k_ch) ^ (k_row & 7)) << 4)) = rk0;
     *(u32x4*)(dst + (((k_ch + 1) ^ (k_row & 7)) << 4)) = rk1;
-    // V^T[d][key]: pair the two keys of a lane pair into one dword per d (quad_perm 1,0,3,2 swap):
-    // even-key lanes write rows d0+2e, odd-key lanes rows d0+2e+1 -> 8 ds_write_b32 per thread
-    const uint32_t w[8] = {rv0.x, rv0.y, rv0.z, rv0.w, rv1.x, rv1.y, rv1.z, rv1.w};
-    const bool odd = v_key & 1;
-    uint32_t* vt = (uint32_t*)sVt[buf];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const uint32_t x = w[e];
-      const uint32_t y = (uint32_t)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xf, 0xf, false);
-      const uint32_t out = odd ? ((y >> 16) | (x & 0xffff0000u)) : ((x & 0xffffu) | (y << 16));
-      const int row = v_d0 + 2 * e + (odd ? 1 : 0);
-      vt[(row * VS + (v_key & ~1)) >> 1] = out;
-    }
+    // V row-major: two 16-byte stores (r03 transposed here: 8 DPP moves + bit merges + 8 ds_write_b32 per thread)
+    uint16_t* vd = sV[buf] + v_key * VS + v_d0;
+    *(u32x4*)vd = rv0;
+    *(u32x4*)(vd + 8) = rv1;
   };
 
   const int ntile = (p.nk + BKV - 1) / BKV;
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(const vgen_attn_args p, i
     const bool more = t + 1 < ntile;
     if (more) gload(kv0 + BKV);
     const unsigned char* cK = sK[buf];
-    const uint16_t* cV = sVt[buf];
+    const uint16_t* cV = sV[buf];
 
     // ---- S^T = K Q^T for both query fragments; K fragments shared ------------------------
     f32x4 s[2][4];
@@ -234,9 +240,11 @@ __global__ __launch_bounds__(256, 2) void flash_kernel(const vgen_attn_args p, i
     for (int st = 0; st < 2; ++st)
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
-        const uint16_t* vr = cV + (d * 16 + lr) * VS + st * 32 + lq * 4;
-        const u32x2 lo = *(const u32x2*)vr;
-        const u32x2 hi = *(const u32x2*)(vr + 16);
+        // A fragment V^T[d = 16 d + lr][keys 32 st + 4 lq + j | 32 st + 16 + 4 lq + j]: two transpose reads of [4 keys][16 d]
+        // blocks; as a SOURCE lane this lane supplies row (lr >> 2), columns 4 (lr & 3) .. + 3 of its group's block
+        const uint16_t* va = cV + (st * 32 + lq * 4 + (lr >> 2)) * VS + d * 16 + (lr & 3) * 4;
+        const u32x2 lo = lds_read_tr16(va);
+        const u32x2 hi = lds_read_tr16(va + 16 * VS);
         const u32x4 vfrag = {lo.x, lo.y, hi.x, hi.y};
         o_acc[0][d] = T::mfma32(vfrag, pb[0][st], o_acc[0][d]);
         o_acc[1][d] = T::mfma32(vfrag, pb[1][st], o_acc[1][d]);
@@ -344,11 +352,9 @@ __global__ __launch_bounds__(256, MINB) void temporal_kernel(const vgen_attn_arg
 
 #pragma unroll
   for (int d = 0; d < 4; ++d) {
-    // A operand: V^T[d*16 + lr][key = 4*lq + r]
-    const uint16_t* vr = &sV[wave][(lq * 4) * VS + d * 16 + lr];
-    u32x2 vfrag;
-    vfrag.x = (uint32_t)vr[0] | ((uint32_t)vr[VS] << 16);
-    vfrag.y = (uint32_t)vr[2 * VS] | ((uint32_t)vr[3 * VS] << 16);
+    // A operand: V^T[d*16 + lr][key = 4*lq + r] — one transpose read of the [4 keys][16 d] block of this 16-lane group
+    // (r03: four ds_read_u16 + two merges per fragment)
+    const u32x2 vfrag = lds_read_tr16(&sV[wave][(lq * 4 + (lr >> 2)) * VS + d * 16 + (lr & 3) * 4]);
     f32x4 o = {0, 0, 0, 0};
     o = T::mfma16(vfrag, pb, o);  // O^T[d*16 + 4*lq + r][query = lr]
     if (live && lr < p.nq)
