@@ -28,6 +28,10 @@ for f in ("bench_partition_eager", "bench_partition_eager_rccl", "bench_partitio
     except Exception as e:
         print(f, "FAILED", e)
 PY
+# the N > 1 launch line of bench.py itself, two ranks sharing the one device over gloo (functional: RCCL refuses two ranks per GPU)
+VGEN_BENCH_ONE_DEVICE=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
+  $R/bench.py --gpus 2 --backend gloo --steps 6 --warmup 2 --no-cpu-baseline --no-vae --no-roofline --no-e2e > $O/bench_2ranks_one_device.json 2> $O/bench_2ranks_one_device.err
+tail -c 600 $O/bench_2ranks_one_device.json; tail -2 $O/bench_2ranks_one_device.err
 rm -rf /tmp/prof_kt
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- $B --steps 5 --warmup 2 > $O/prof_bench.json 2> /dev/null
 python $R/tools/rocprof_summary.py $(ls /tmp/prof_kt/*/*kernel_stats.csv | head -1) $O/kernel_stats_summary.csv | head -24
