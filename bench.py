@@ -255,12 +255,27 @@ class StepTimer:
         return dt_s, xt
 
 
-def _emit(res, world):
+def _finish(res, world):
+    """Leave together, then print the ONE JSON line LAST: RCCL writes its version banner to stdout through C stdio, which —
+    redirected to a file or a pipe — is flushed at exit, i.e. after a line printed from Python (seen in r04: the banner
+    followed the JSON and a last-line parser read 'Librccl path : ...')."""
+    import ctypes
     import torch.distributed as dist
-    print(json.dumps(res), flush=True)
     if world > 1:
-        dist.barrier()
+        dist.barrier()                      # rank 0 ran the untimed extras (roofline pass, VAE); leave together
+    if dist.is_initialized():
         dist.destroy_process_group()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:                       # noqa: BLE001
+        pass
+    sys.stdout.flush()
+    if res is not None:
+        print(json.dumps(res), flush=True)
+
+
+def _emit(res, world):
+    _finish(res, world)
 
 
 def run_videolcm(args, dev, model, world, rank):
@@ -441,6 +456,10 @@ def main():
     args = ap.parse_args()
     if args.no_graph:
         os.environ["VGEN_GRAPH"] = "0"
+    if os.environ.get("VGEN_BENCH_WATCHDOG"):
+        # diagnosis aid: dump every thread's stack and exit if the run is still going after N seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["VGEN_BENCH_WATCHDOG"]), exit=True)
 
     import torch.distributed as dist
     from vgen_amd import ops
@@ -476,8 +495,7 @@ def main():
 
     if args.config == "tft2v_sr600":
         res = run_two_stage(args, dev, world, rank)
-        if rank == 0:
-            _emit(res, world)
+        _finish(res if rank == 0 else None, world)
         return
     cfg = CONFIGS[args.config]
     C, F, H, W = cfg["latent"]
@@ -492,8 +510,7 @@ def main():
         drop_masters(model, dev)
     if args.config == "videolcm":
         res = run_videolcm(args, dev, model, world, rank)
-        if rank == 0:
-            _emit(res, world)
+        _finish(res if rank == 0 else None, world)
         return
 
     diff = DiffusionDDIM(**DDIM)
@@ -922,12 +939,7 @@ def main():
                                "vae_sample": f"one 256x448 frame through the fp32 AutoencoderKL decoder ({kind}): {vae_s:.2f} s",
                                "sample": f"{what}: one forward of the full-size UNet on the 16-frame latent "
                                          f"[1,4,16,32,56]: {fwd_s:.1f} s; a CFG step is two forwards"}
-    if rank == 0:
-        print(json.dumps(res), flush=True)
-    if world > 1:
-        dist.barrier()                      # rank 0 ran the untimed extras (roofline pass, VAE); leave together
-    if dist.is_initialized():
-        dist.destroy_process_group()
+    _finish(res if rank == 0 else None, world)
 
 
 if __name__ == "__main__":

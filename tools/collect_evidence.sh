@@ -24,7 +24,7 @@ python - <<PY
 import json
 for f in ("bench_partition_eager", "bench_partition_eager_rccl", "bench_partition_graph_rccl"):
     try:
-        d = json.loads(open("$O/%s.json" % f).read().strip().splitlines()[-1]); print(f, d["value"], d["ms_per_step"], d["config"]["hipgraph"])
+        d = json.loads([l for l in open("$O/%s.json" % f).read().splitlines() if l.startswith('{"metric"')][-1]); print(f, d["value"], d["ms_per_step"], d["config"]["hipgraph"])
     except Exception as e:
         print(f, "FAILED", e)
 PY

@@ -14,7 +14,12 @@ tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 prec = sys.argv[2] if len(sys.argv) > 2 else "mixed"
 dtype = sys.argv[3] if len(sys.argv) > 3 else "fp16"
 P = os.path.join(ROOT, "profiles")
-bench = json.loads(open(os.path.join(E, "bench.json")).read().strip().splitlines()[-1])
+def bench_line(path):
+    """the bench's JSON line (older runs: RCCL's banner could follow it on stdout)"""
+    return json.loads([ln for ln in open(path).read().splitlines() if ln.startswith('{"metric"')][-1])
+
+
+bench = bench_line(os.path.join(E, "bench.json"))
 json.dump(bench, open(os.path.join(P, f"{tag}_bench_evidence.json"), "w"), indent=1)
 shutil.copy(os.path.join(E, "kernel_stats_summary.csv"), os.path.join(P, f"{tag}_kernel_stats_summary.csv"))
 pmc = json.load(open(os.path.join(E, "pmc_classes.json")))
@@ -37,6 +42,10 @@ print(json.dumps(out, indent=1))
 for f, dst in (("pytest_gpu.log", "pytest_gpu.log"), ("smoke.log", "smoke.log"), ("parity.json", "parity.json"),
                ("bench_partition_eager.json", "bench_partition_eager.json"),
                ("bench_partition_eager_rccl.json", "bench_partition_eager_rccl.json"),
-               ("bench_partition_graph_rccl.json", "bench_partition_graph_rccl.json")):
+               ("bench_partition_graph_rccl.json", "bench_partition_graph_rccl.json"),
+               ("bench_2ranks_one_device.json", "bench_2ranks_one_device.json")):
     if os.path.exists(os.path.join(E, f)):
-        shutil.copy(os.path.join(E, f), os.path.join(P, f"{tag}_{dst}"))
+        if f.startswith("bench_"):
+            json.dump(bench_line(os.path.join(E, f)), open(os.path.join(P, f"{tag}_{dst}"), "w"), indent=1)
+        else:
+            shutil.copy(os.path.join(E, f), os.path.join(P, f"{tag}_{dst}"))
