@@ -393,7 +393,7 @@ __global__ __launch_bounds__(GN_THREADS) void gn_apply_kernel(
 // Larger slices stay on the streaming pipeline: a single block per slice is latency-bound (one CU
 // pulls ~20 GB/s with 16 KiB in flight; measured 51 us vs 26 us on [2 x 1792 x 1280]).
 // Fixed reduction order: wave butterflies, then the wave partials in index order.
-constexpr int GNF_THREADS = 512;
+constexpr int GNF_THREADS = 512;         // r04 same-box A/B of the whole step: 256 threads +0.3 %, 1024 +0.35 % (profiles/r04f_ab_gnf_threads.jsonl)
 constexpr int GNF_LDS_FLOATS = 24576;   // 96 KiB of the CU's 160 KiB
 
 __device__ __forceinline__ float gnf_block_sum(float v, float* red) {
