@@ -274,10 +274,6 @@ def _finish(res, world):
         print(json.dumps(res), flush=True)
 
 
-def _emit(res, world):
-    _finish(res, world)
-
-
 def run_videolcm(args, dev, model, world, rank):
     """BASELINE config 4 as stated: whole videos through the 4-step `LCMScheduler.sample_loop` + the 16-frame decode
     ("decode-bound, exercises VAE kernels").  Every video is a NEW prompt (fresh context tensor, as a new caption through

@@ -223,9 +223,9 @@ class UnitPartition:
 
     # -- r04: the whole partitioned DDIM step as one launch sequence --------------------------------------------------
     def fused_layout(self, P: int, G: int):
-        """(owner rank -> list of prompts it owns in slot order) when the gathered buffer splits into per-rank blocks the
-        update kernel can address directly ('prompt' layout: rank r's block is [y of its P/W prompts | u of them]; or ONE
-        prompt whose G = W = 2 branches sit on two ranks), else None (the eager path handles everything)."""
+        """'prompt' | 'pair' when the gathered buffer splits into per-rank blocks the update kernel can address directly
+        ('prompt': rank r's block is [y of its P/W prompts | u of them]; 'pair': ONE prompt whose G = W = 2 branches sit on
+        two ranks), else None (the eager gather + update path handles everything)."""
         W = self.world
         if G == 2 and self.layout(P, G) == "prompt":
             return "prompt"
