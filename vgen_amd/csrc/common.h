@@ -13,6 +13,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4_t;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
@@ -60,8 +61,13 @@ struct F16 {
   static __device__ __forceinline__ uint16_t from_f32(float f) {
     return __builtin_bit_cast(uint16_t, (_Float16)f);
   }
+  // r04: two fp32 -> packed fp16 in ONE instruction (gfx950 v_cvt_pk_f16_f32, round-to-nearest-even) through the vector
+  // conversion the compiler lowers itself (see BF16::pack2 for why not inline asm).  The scalar form it replaces compiled
+  // to v_cvt_f16_f32 + v_cvt_f16_f32_sdwa + v_or_b32 per pair: 48 of the ~100 VALU instructions of flash_kernel's
+  // probability block, and three times the conversion work of every 16-bit tap-GEMM / norm epilogue.  Bit-identical.
   static __device__ __forceinline__ uint32_t pack2(float lo, float hi) {
-    return (uint32_t)from_f32(lo) | ((uint32_t)from_f32(hi) << 16);
+    const f32x2 v = {lo, hi};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, f16x2_t));
   }
   static __device__ __forceinline__ f32x4 mfma32(u32x4 a, u32x4 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8_t, a),
