@@ -229,7 +229,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
 
   // Branch-free regather (r03).  The first version compiled `ok ? A + row * lda : zline` with 64-bit row / stride
   // products into a diamond per piece (350 instructions in ~25 basic blocks, exec-mask branches): the s_memtime probe
-  // (tools/stamp_probe.py, profiles/r03l_kstep_stamps_base.json) put the pointer step of a 3x3 conv at ~300 cycles per
+  // (r03's in-kernel s_memtime probe, profiles/r03l_kstep_stamps_base.json) put the pointer step of a 3x3 conv at ~300 cycles per
   // K-step averaged over the tap's K-tiles — on the matrix-phase side of the ping-pong, i.e. on its critical path.  Now:
   // 32-bit source row (validated on the host), one v_mad_u64_u32 per piece, predication instead of branches (~150
   // instructions): whole step -1.2 / -1.3 % (mixed / single-pass) in a same-box A/B, profiles/r03m_ab_gather.jsonl.
