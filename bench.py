@@ -406,7 +406,9 @@ def run_two_stage(args, dev, world, rank):
                    "parallelism": "single GPU", "weights": "seeded synthetic (device-side random init)",
                    "smoke_run": steps1 is not None,
                    "note": "one video, cold sessions (setup + graph capture inside the timed region, as a one-shot engine "
-                           "run pays them); weight synthesis of the second model excluded"},
+                           "run pays them); weight synthesis of the second model excluded; stage 1 runs the text + image "
+                           "compositions — with the whole vcomposer list at this shape precision='mixed' measures 1.01e-3 "
+                           "(tests/golden/unet_vcomposer_full.pt): run stage 1 with --precision high for <= 1e-3"},
         "seconds_per_video": round(total, 3), "stages": times,
         "finite": fin1 and bool(torch.isfinite(out).all()), "video_shape": list(video.shape),
     }

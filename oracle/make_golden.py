@@ -223,6 +223,42 @@ def make_vcomposer(R):
     print("unet_vcomposer_tiny", tuple(out.shape), float(out.std()))
 
 
+def vcomposer_conds(seed, F, H, W):
+    """the six spatial conditions of the vcomposer list at pixel resolution, regenerated from a seed (the fixture cannot
+    carry 350 MB of maps); values are fp16-representable.  Order = the order tests/full_cases.py regenerates them in."""
+    g = torch.Generator("cpu").manual_seed(seed)
+    mk = lambda c: torch.randn(1, c, F, H, W, generator=g).half().float()
+    conds = dict(depth=mk(1), sketch=mk(1), single_sketch=mk(1), motion=mk(2), local_image=mk(3), masked=mk(4))
+    image = torch.randn(1, 1, 1024, generator=g)
+    return conds, image
+
+
+def make_vcomposer_full(R):
+    """FULL-WIDTH UNetSD_TFT2V with the composition list of configs/tft2v_vcomposer_infer.yaml:74 at BASELINE config 5's
+    first-stage shape: 32 frames 896 x 512, latent [1,4,32,64,112] (78 TFLOP on the CPU) — six spatial condition stems at
+    pixel resolution summed into the concat channels, image token, 32-frame temporal attention (the flash kernel's path:
+    more than 16 frames)."""
+    import time
+    import types
+    cfgm = dict(UNET_T2V, concat_dim=8, num_tokens=4, training=False)
+    cfg = types.SimpleNamespace(video_compositions=list(VCOMPOSER), resolution=[896, 512])
+    ref = R["MODEL"].build(dict(type="UNetSD_TFT2V", config=cfg, **cfgm)).eval()
+    shapes = torch_ref.shapes_of(ref)
+    ref.load_state_dict(torch_ref.synth_state_dict(shapes, seed=0), strict=True)
+    g = torch.Generator("cpu").manual_seed(8896)
+    x = torch.randn(1, 4, 32, 64, 112, generator=g)
+    y = torch.randn(1, 77, 1024, generator=g)
+    conds, image = vcomposer_conds(8897, 32, 512, 896)
+    t = torch.tensor([601])
+    t0 = time.time()
+    with torch.no_grad():
+        out = ref(x, t, y=y, image=image, **conds)
+    print("unet_vcomposer_full: %.1f s, std %.4f" % (time.time() - t0, float(out.std())))
+    torch.save(dict(cfg=cfgm, comps=list(VCOMPOSER), resolution=[896, 512], seed=0, shapes=shapes, input_seed=8896,
+                    cond_seed=8897, t=t, out_sub=_sub(out), out_norm=float(out.norm())),
+               os.path.join(GOLD, "unet_vcomposer_full.pt"))
+
+
 @torch.no_grad()
 def make_vae_full2(R):
     """Full-size SD AutoencoderKL fixtures the r02 set lacked: `encode` moments + the stochastic
@@ -696,7 +732,7 @@ def main():
         make_i2vgen_full(R)
         return
     extra = dict(t2v_extra=make_t2v_extra, videolcm_full=make_videolcm_full, tft2v_full=make_tft2v_full,
-                 sr600_full=make_sr600_full)
+                 sr600_full=make_sr600_full, vcomposer_full=make_vcomposer_full)
     if args.only in extra:
         extra[args.only](R)
         return

@@ -10,6 +10,8 @@ fixture (oracle/make_golden.py --only ...)   model / shape                      
   tft2v    unet_tft2v_full.pt    UNetSD_TFT2V ['text','image'] [1,4,16,64,112], t = 401            unet_tf2tv.py:538-777
   sr600    unet_sr600_full.pt    UNetSD_SR600 [1,4,32,90,160], t = 699                              unet_sr600.py:220-299
   i2vgen   unet_i2vgen_full.pt   UNetSD_I2VGen [1,4,16,88,160], t = 601 (r03)                       unet_i2vgen.py:243-262
+  vcomposer unet_vcomposer_full.pt UNetSD_TFT2V, the 8-entry vcomposer composition list, [1,4,32,64,112] (32 frames 896x512),
+                                 six pixel-resolution condition maps regenerated from a seed, t = 601   unet_tf2tv.py:538-777
 """
 import os
 import types
@@ -21,8 +23,9 @@ from oracle import torch_ref
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FIX = {"t2v": "unet_t2v_full.pt", "t2v_b": "unet_t2v_full_b.pt", "t2v_c": "unet_t2v_full_c.pt",
        "videolcm": "unet_videolcm_full.pt", "tft2v": "unet_tft2v_full.pt", "sr600": "unet_sr600_full.pt",
-       "i2vgen": "unet_i2vgen_full.pt"}
-SHAPE = {"tft2v": (1, 4, 16, 64, 112), "sr600": (1, 4, 32, 90, 160), "i2vgen": (1, 4, 16, 88, 160)}
+       "i2vgen": "unet_i2vgen_full.pt", "vcomposer": "unet_vcomposer_full.pt"}
+SHAPE = {"tft2v": (1, 4, 16, 64, 112), "sr600": (1, 4, 32, 90, 160), "i2vgen": (1, 4, 16, 88, 160),
+         "vcomposer": (1, 4, 32, 64, 112)}
 
 
 def load(name):
@@ -34,8 +37,9 @@ def build(name, g, precision, dev="cpu", dtname="fp16"):
     from vgen_amd.unet_i2vgen import UNetSD_I2VGen
     from vgen_amd.unet_videolcm import UNetSD_TFT2V, UNetSD_VideoLCM
     kw = dict(g["cfg"])
-    cls = {"videolcm": UNetSD_VideoLCM, "tft2v": UNetSD_TFT2V, "sr600": UNetSD_SR600, "i2vgen": UNetSD_I2VGen}.get(name, UNetSD_T2VBase)
-    if name in ("videolcm", "tft2v"):
+    cls = {"videolcm": UNetSD_VideoLCM, "tft2v": UNetSD_TFT2V, "vcomposer": UNetSD_TFT2V, "sr600": UNetSD_SR600,
+           "i2vgen": UNetSD_I2VGen}.get(name, UNetSD_T2VBase)
+    if name in ("videolcm", "tft2v", "vcomposer"):
         kw["config"] = types.SimpleNamespace(video_compositions=g["comps"], resolution=g["resolution"])
     with torch.device("meta"):
         m = cls(**kw, compute_dtype=dtname, precision=precision)
@@ -55,6 +59,13 @@ def inputs(name, g):
     if name == "i2vgen":
         kw["local_image"] = torch.randn(1, 4, 88, 160, generator=gen)
         kw["fps"] = g["fps"]
+    if name == "vcomposer":
+        # the condition maps are regenerated from their own seed, in the generator order of oracle/make_golden.py::vcomposer_conds
+        cg = torch.Generator("cpu").manual_seed(g["cond_seed"])
+        F_, (W_, H_) = SHAPE[name][2], g["resolution"]
+        mk = lambda c: torch.randn(1, c, F_, H_, W_, generator=cg).half().float()
+        kw.update(depth=mk(1), sketch=mk(1), single_sketch=mk(1), motion=mk(2), local_image=mk(3), masked=mk(4))
+        kw["image"] = torch.randn(1, 1, 1024, generator=cg)
     return x, kw
 
 

@@ -258,9 +258,10 @@ class UNetSD_T2VBase(nn.Module):
         # (DESIGN §4.1); set before the first forward / pack().
         # What "meets 1e-3" rests on: seeded SYNTHETIC weights — pretrained checkpoints are not available
         # offline — on the full-width models: t2v 8.34e-4 / 8.19e-4 (t = 501) / 7.31e-4 (Student-t weights), I2VGen
-        # 8.95e-4, and the VideoLCM / TFT2V / SR600 fixtures of tests/full_cases.py.  It is a property of 4-level,
-        # dim-320 trunks, not of the mode: on the 3-level dim-64 test model the level rule gives 1.1e-3 and even "high"
-        # only 9.2e-4 (what is left there is activation rounding).  A drop-in user pays ~1.1x the single-pass step and
+        # 8.95e-4, and the VideoLCM / TFT2V / SR600 fixtures of tests/full_cases.py.  It is a property of those trunks,
+        # not of the mode: on the 3-level dim-64 test model the level rule gives 1.1e-3 and even "high" only 9.2e-4
+        # (what is left there is activation rounding), and the vcomposer composition list at 32 frames 896 x 512
+        # (BASELINE config 5, stage 1) measures 1.01e-3 in "mixed", 8.6e-4 in "high" — use "high" there.  A drop-in user pays ~1.1x the single-pass step and
         # the [W_hi | W_lo] copies of the level-0 weights (~0.3 GB) for it; precision="fast" is the reference's own
         # arithmetic (1.33e-3 where its autocast forward lands at 2.10e-3).
         self.precision = precision or "mixed"
