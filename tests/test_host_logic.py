@@ -510,3 +510,20 @@ def test_vae_attention_query_blocks(emu_backend):
     with pytest.raises(NotImplementedError):
         AutoencoderKL(ddconfig=g["ddconfig"], embed_dim=8)
 
+
+
+def test_composer_trunks_default_to_high_precision_with_spatial_condition_stems():
+    """r04: precision=None is "mixed" for every trunk — except composer trunks whose composition list carries spatial
+    condition stems: the full-width vcomposer fixture measures 1.01e-3 in "mixed", 8.6e-4 in "high" (DESIGN §4.1).  An
+    explicit keyword wins."""
+    import types
+    from vgen_amd.unet_videolcm import UNetSD_TFT2V, UNetSD_VideoLCM
+    g = gold("unet_vcomposer_tiny.pt")
+    mk = lambda cls, comps, **kw: cls(**g["cfg"], config=types.SimpleNamespace(video_compositions=comps, resolution=g["resolution"]), **kw)
+    with torch.device("meta"):
+        assert mk(UNetSD_TFT2V, ["text", "image"]).precision == "mixed"
+        assert mk(UNetSD_VideoLCM, ["text"]).precision == "mixed"
+        assert mk(UNetSD_TFT2V, g["comps"]).precision == "high"
+        assert mk(UNetSD_VideoLCM, ["text", "histogram", "canny"]).precision == "high"
+        assert mk(UNetSD_TFT2V, g["comps"], precision="fast").precision == "fast"
+        assert mk(UNetSD_TFT2V, g["comps"], precision="mixed").precision == "mixed"
