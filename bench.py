@@ -21,8 +21,8 @@ warm-up + capture), like weight loading.
 
 HEADLINE MODE = a mode that meets the north-star's tolerance: fp16 operands, precision="mixed" — packed weights as
 W_hi + W_lo pairs (one dual-W tap-GEMM launch per layer) in the blocks of the FULL-RESOLUTION level (encoder and decoder
-level 0, + the context K/V projection and the head conv), where 82 % of the output's sensitivity to weight rounding sits
-(DESIGN §4.1): UNet output <= 1e-3 rel-L2 of the reference's fp32 forward — measured on seeded synthetic weights (no
+level 0, + the context K/V projection and the head conv; the FeedForward pair and the cross-attention query stay single-pass:
+UNetSD_T2VBase.MIXED_SINGLE_KINDS), where 82 % of the output's sensitivity to weight rounding sits: UNet output <= 1e-3 rel-L2 of the reference's fp32 forward — measured on seeded synthetic weights (no
 checkpoints offline): three full-size t2v fixtures (two weight recipes, three timesteps) and the full-width I2VGen /
 VideoLCM / TFT2V / SR600 fixtures; on the 3-level dim-64 test model the same rule lands at 1.1e-3.
 `parity.unet_rel_l2` is COMPUTED IN THIS RUN (max over the three t2v fixtures): the timed model evaluates the golden

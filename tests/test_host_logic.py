@@ -137,6 +137,18 @@ def test_mixed_precision_splits_by_resolution_level(emu_backend):
             n_split += has
             n_plain += not has
     assert n_split > 0 and n_plain > 0
+    # r04: inside the two-term levels the FeedForward pair and the cross-attention query stay single-pass
+    # (UNetSD_T2VBase.MIXED_SINGLE_KINDS); "mixed:...:all" and "high" keep them two-term
+    dw = lambda w: getattr(w[0] if isinstance(w, tuple) else w, "vgen_dw", None) is not None
+    st0 = next(n for n, mod in mm.named_modules() if type(mod).__name__ == "_SpatialTransformerP" and lv[".".join(n.split(".")[:2])] == ("enc", 0))
+    tb = P[st0]["tb"]
+    assert dw(tb["qkv1"]) and dw(tb["o1"]) and dw(tb["o2"]) and dw(P[st0]["pin"]) and dw(P[st0]["pout"])
+    assert not dw(tb["ff1"]) and not dw(tb["ff2"]) and not dw(tb["q2"])
+    ma = UNetSD_T2VBase(**g["cfg"], compute_dtype="fp16", precision="mixed:e0d0:all").eval()
+    ma.load_state_dict(sd, strict=True)
+    assert ma.precision == "mixed" and ma.MIXED_SINGLE_KINDS == () and ma.MIXED_LEVELS["enc"] == (0,)
+    tba = ma.pack()[st0]["tb"]
+    assert dw(tba["ff1"]) and dw(tba["ff2"]) and dw(tba["q2"])
     e_fast = rel_l2(m(g["x"], g["t"], y=g["y"]), g["out"])
     mh = UNetSD_T2VBase(**g["cfg"], compute_dtype="fp16", precision="high").eval()
     mh.load_state_dict(sd, strict=True)

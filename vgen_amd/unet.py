@@ -257,8 +257,8 @@ class UNetSD_T2VBase(nn.Module):
         # "mixed" (default): the same, with two-term weights only at the full-resolution level: 8.3e-4 at ~1.1x
         # (DESIGN §4.1); set before the first forward / pack().
         # What "meets 1e-3" rests on: seeded SYNTHETIC weights — pretrained checkpoints are not available
-        # offline — on the full-width models: t2v 8.34e-4 / 8.19e-4 (t = 501) / 7.31e-4 (Student-t weights), I2VGen
-        # 8.95e-4, and the VideoLCM / TFT2V / SR600 fixtures of tests/full_cases.py.  It is a property of those trunks,
+        # offline — on the full-width models: t2v 8.59e-4 / 8.44e-4 (t = 501) / 7.39e-4 (Student-t weights), I2VGen
+        # 9.1e-4, and the VideoLCM / TFT2V / SR600 fixtures of tests/full_cases.py.  It is a property of those trunks,
         # not of the mode: on the 3-level dim-64 test model the level rule gives 1.1e-3 and even "high" only 9.2e-4
         # (what is left there is activation rounding), and the vcomposer composition list at 32 frames 896 x 512
         # (BASELINE config 5, stage 1) measures 1.01e-3 in "mixed", 8.6e-4 in "high" — use "high" there.  A drop-in user pays ~1.1x the single-pass step and
@@ -266,9 +266,13 @@ class UNetSD_T2VBase(nn.Module):
         # arithmetic (1.33e-3 where its autocast forward lands at 2.10e-3).
         self.precision = precision or "mixed"
         if self.precision.startswith("mixed:"):
-            # "mixed:e0d01": two-term weights in encoder level 0 and decoder levels 0, 1 ("m3": the middle block at level 3)
+            # "mixed:e0d01": two-term weights in encoder level 0 and decoder levels 0, 1 ("m3": the middle block at level 3);
+            # a trailing ":all" also keeps the FeedForward / cross-attention-query weights two-term (MIXED_SINGLE_KINDS)
             import re
             spec = self.precision.split(":", 1)[1]
+            if spec.endswith(":all") or spec == "all":
+                self.MIXED_SINGLE_KINDS = ()
+                spec = spec[:-4] if spec.endswith(":all") else "e0d0"
             assert re.fullmatch(r"(?:[edmt]\d*)*", spec), f"precision={self.precision!r}"
             lv = {"e": (), "d": (), "m": (), "t": ()}
             for side, digits in re.findall(r"([edmt])(\d*)", spec):
@@ -382,6 +386,14 @@ class UNetSD_T2VBase(nn.Module):
     # resolution levels (0 = full) whose blocks carry two-term weights: encoder / middle / decoder side, and "tx": levels
     # where only the Spatial / TemporalTransformer blocks do (their launches are the cheap ones to run dual-W)
     MIXED_LEVELS = {"enc": (0,), "mid": (), "dec": (0,), "tx": ()}
+    # r04: layer kinds that stay SINGLE-pass inside the two-term levels of "mixed".  Stripping one kind at a time from the
+    # level-0 set (tools/mixed_kind_sensitivity.py, full-size t2v on the ABI emulator: profiles/r04_mixed_kind_sensitivity.json)
+    # adds, in units of 1e-8 of error energy on a base of 69: qkv 13.5, conv2 11.4, Down / Up / K,V / head 11.0, pout 10.7,
+    # pin 10.3, temporal convs 9.2, o-proj 6.3, conv1 4.6 — and the FeedForward pair only 3.2 (ff1) + 1.4 (ff2), the
+    # cross-attention query nothing (-0.3: noise): the GEGLU gate and the 4d-wide average of ff2 damp a weight rounding
+    # that every other layer passes on.  Those are also the most expensive launches to run dual-W (the level-0 GEGLU
+    # 57344 x 2560 x 320 alone +0.72 ms per step: it loses the two-blocks-per-CU shape).  "high" keeps every weight two-term.
+    MIXED_SINGLE_KINDS = ("ff1", "ff2", "q2")
 
     def _block_levels(self):
         """top-level block name ('input_blocks.3', 'middle_block', 'output_blocks.7') -> (side, resolution level), the
@@ -500,13 +512,18 @@ class UNetSD_T2VBase(nn.Module):
             d["qkv1"] = pack_linear(torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0), dt)
             d["o1"] = (pack_linear(a1.to_out[0].weight, dt), _f32(a1.to_out[0].bias))
             a2 = tb.attn2
+            single = self.MIXED_SINGLE_KINDS if self.precision == "mixed" else ()
+            keep = lambda kind: split_weights(_SPLIT_WEIGHTS and kind not in single)
             if cross:
-                d["q2"] = pack_linear(a2.to_q.weight, dt)
+                with keep("q2"):
+                    d["q2"] = pack_linear(a2.to_q.weight, dt)
             else:
                 d["qkv2"] = pack_linear(torch.cat([a2.to_q.weight, a2.to_k.weight, a2.to_v.weight], 0), dt)
             d["o2"] = (pack_linear(a2.to_out[0].weight, dt), _f32(a2.to_out[0].bias))
-            d["ff1"] = pack_geglu(tb.ff.net[0].proj.weight, tb.ff.net[0].proj.bias, dt)
-            d["ff2"] = (pack_linear(tb.ff.net[2].weight, dt), _f32(tb.ff.net[2].bias))
+            with keep("ff1"):
+                d["ff1"] = pack_geglu(tb.ff.net[0].proj.weight, tb.ff.net[0].proj.bias, dt)
+            with keep("ff2"):
+                d["ff2"] = (pack_linear(tb.ff.net[2].weight, dt), _f32(tb.ff.net[2].bias))
             return d
 
         def pack_tx(m, cross):
