@@ -133,22 +133,35 @@ def test_mixed_precision_splits_by_resolution_level(emu_backend):
             top = "middle_block" if name.startswith("middle_block") else ".".join(name.split(".")[:2])
             side, level = lv[top]
             has = getattr(first_weight(P[name]), "vgen_dw", None) is not None
-            assert has == (level == 0 and side != "mid"), (name, side, level, has)
+            # first_weight: conv1 of a ResBlock, proj_in of a transformer — level 0: every kind; level 1: the r04 extra
+            # kinds (conv2 / proj_in / proj_out: MIXED_EXTRA_KINDS), so proj_in yes, conv1 no
+            want = (level == 0 and side != "mid") or (level == 1 and side != "mid" and type(mod).__name__ != "_ResBlockP")
+            assert has == want, (name, side, level, has)
             n_split += has
             n_plain += not has
     assert n_split > 0 and n_plain > 0
     # r04: inside the two-term levels the FeedForward pair and the cross-attention query stay single-pass
     # (UNetSD_T2VBase.MIXED_SINGLE_KINDS); "mixed:...:all" and "high" keep them two-term
     dw = lambda w: getattr(w[0] if isinstance(w, tuple) else w, "vgen_dw", None) is not None
-    st0 = next(n for n, mod in mm.named_modules() if type(mod).__name__ == "_SpatialTransformerP" and lv[".".join(n.split(".")[:2])] == ("enc", 0))
+    lvl = lambda n: lv["middle_block" if n.startswith("middle_block") else ".".join(n.split(".")[:2])]
+    st0 = next(n for n, mod in mm.named_modules() if type(mod).__name__ == "_SpatialTransformerP" and lvl(n) == ("enc", 0))
     tb = P[st0]["tb"]
     assert dw(tb["qkv1"]) and dw(tb["o1"]) and dw(tb["o2"]) and dw(P[st0]["pin"]) and dw(P[st0]["pout"])
     assert not dw(tb["ff1"]) and not dw(tb["ff2"]) and not dw(tb["q2"])
+    # ... and at level 1 exactly the extra kinds are two-term: the ResBlock out-conv, proj_in, proj_out
+    assert mm.MIXED_EXTRA_KINDS == {1: ("conv2", "pin", "pout")}
+    rb1 = next(n for n, mod in mm.named_modules() if type(mod).__name__ == "_ResBlockP" and lvl(n) == ("enc", 1))
+    st1 = next(n for n, mod in mm.named_modules() if type(mod).__name__ == "_SpatialTransformerP" and lvl(n) == ("dec", 1))
+    assert dw(P[rb1]["conv2"]) and not dw(P[rb1]["conv1"]) and not dw(P[rb1]["tconv1"])
+    assert dw(P[st1]["pin"]) and dw(P[st1]["pout"]) and not dw(P[st1]["tb"]["qkv1"]) and not dw(P[st1]["tb"]["o1"])
+    rbm = next(n for n, mod in mm.named_modules() if type(mod).__name__ == "_ResBlockP" and n.startswith("middle_block"))
+    assert not dw(P[rbm]["conv2"])
     ma = UNetSD_T2VBase(**g["cfg"], compute_dtype="fp16", precision="mixed:e0d0:all").eval()
     ma.load_state_dict(sd, strict=True)
-    assert ma.precision == "mixed" and ma.MIXED_SINGLE_KINDS == () and ma.MIXED_LEVELS["enc"] == (0,)
-    tba = ma.pack()[st0]["tb"]
-    assert dw(tba["ff1"]) and dw(tba["ff2"]) and dw(tba["q2"])
+    assert ma.precision == "mixed" and ma.MIXED_SINGLE_KINDS == () and ma.MIXED_EXTRA_KINDS == {} and ma.MIXED_LEVELS["enc"] == (0,)
+    Pa = ma.pack()
+    tba = Pa[st0]["tb"]
+    assert dw(tba["ff1"]) and dw(tba["ff2"]) and dw(tba["q2"]) and not dw(Pa[rb1]["conv2"]) and not dw(Pa[st1]["pin"])
     e_fast = rel_l2(m(g["x"], g["t"], y=g["y"]), g["out"])
     mh = UNetSD_T2VBase(**g["cfg"], compute_dtype="fp16", precision="high").eval()
     mh.load_state_dict(sd, strict=True)

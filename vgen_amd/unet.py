@@ -257,8 +257,8 @@ class UNetSD_T2VBase(nn.Module):
         # "mixed" (default): the same, with two-term weights only at the full-resolution level: 8.3e-4 at ~1.1x
         # (DESIGN §4.1); set before the first forward / pack().
         # What "meets 1e-3" rests on: seeded SYNTHETIC weights — pretrained checkpoints are not available
-        # offline — on the full-width models: t2v 8.59e-4 / 8.44e-4 (t = 501) / 7.39e-4 (Student-t weights), I2VGen
-        # 9.1e-4, and the VideoLCM / TFT2V / SR600 fixtures of tests/full_cases.py.  It is a property of those trunks,
+        # offline — on the full-width models (ABI emulator; GPU numbers of the rules that ran there in DESIGN §4.1): t2v
+        # 7.7e-4 / 7.6e-4 (t = 501) / 6.5e-4 (Student-t weights), I2VGen 8.8e-4, VideoLCM / TFT2V / SR600 7.5 - 7.9e-4.  It is a property of those trunks,
         # not of the mode: on the 3-level dim-64 test model the level rule gives 1.1e-3 and even "high" only 9.2e-4
         # (what is left there is activation rounding), and the vcomposer composition list at 32 frames 896 x 512
         # (BASELINE config 5, stage 1) measures 1.01e-3 in "mixed", 8.6e-4 in "high" — use "high" there.  A drop-in user pays ~1.1x the single-pass step and
@@ -271,7 +271,7 @@ class UNetSD_T2VBase(nn.Module):
             import re
             spec = self.precision.split(":", 1)[1]
             if spec.endswith(":all") or spec == "all":
-                self.MIXED_SINGLE_KINDS = ()
+                self.MIXED_SINGLE_KINDS, self.MIXED_EXTRA_KINDS = (), {}
                 spec = spec[:-4] if spec.endswith(":all") else "e0d0"
             assert re.fullmatch(r"(?:[edmt]\d*)*", spec), f"precision={self.precision!r}"
             lv = {"e": (), "d": (), "m": (), "t": ()}
@@ -394,6 +394,14 @@ class UNetSD_T2VBase(nn.Module):
     # that every other layer passes on.  Those are also the most expensive launches to run dual-W (the level-0 GEGLU
     # 57344 x 2560 x 320 alone +0.72 ms per step: it loses the two-blocks-per-CU shape).  "high" keeps every weight two-term.
     MIXED_SINGLE_KINDS = ("ff1", "ff2", "q2")
+    # ... and the reverse move of the same study (tools/mixed_frontier.py: the model packed in "high", any candidate set one
+    # emulated forward away; profiles/r04_mixed_frontier.json): layer kinds that ARE two-term at resolution levels outside
+    # MIXED_LEVELS (encoder and decoder side, not the middle block).  Added to the default rule one at a time at level 1, error
+    # energy in 1e-8 on a base of 73: the ResBlock out-conv (conv2, the residual branch's last layer) -9.7, proj_out -3.9,
+    # temporal convs -3.2, Down / Up convs -2.4, proj_in -2.0, qkv -1.6, conv1 -1.0, ff2 -0.8, o-proj -0.1, ff1 +0.1.
+    # conv2 is five launches per forward at 14 336 rows, proj_in / proj_out twenty 33 us ones at ~1.1x: the three together
+    # buy back more than the FeedForward weights cost (t2v 8.57e-4 -> 7.6e-4 emulated) for an estimated +0.4 ms.
+    MIXED_EXTRA_KINDS = {1: ("conv2", "pin", "pout")}
 
     def _block_levels(self):
         """top-level block name ('input_blocks.3', 'middle_block', 'output_blocks.7') -> (side, resolution level), the
@@ -434,12 +442,29 @@ class UNetSD_T2VBase(nn.Module):
             return False
         if level in self.MIXED_LEVELS[side]:
             return True
+        if side in ("enc", "dec") and self.MIXED_EXTRA_KINDS.get(level):
+            return True                                                   # some kinds only: _kind_on() filters at the pack sites
         if level in self.MIXED_LEVELS.get("tx", ()):
             try:
                 return isinstance(self.get_submodule(name), (_SpatialTransformerP, _TemporalTransformerP))
             except AttributeError:
                 return False
         return False
+
+    def _kind_on(self, name, kind):
+        """Is weight `kind` of module `name` two-term?  (Called inside `with split_weights(self._wants_split(name))`.)"""
+        if not _SPLIT_WEIGHTS or self.precision != "mixed":
+            return _SPLIT_WEIGHTS
+        if kind in self.MIXED_SINGLE_KINDS:
+            return False
+        parts = name.split(".")
+        top = parts[0] if parts[0] == "middle_block" else ".".join(parts[:2])
+        side, level = self._block_levels().get(top, (None, None))
+        if side is None or level in self.MIXED_LEVELS[side]:
+            return True
+        if level in self.MIXED_LEVELS.get("tx", ()) and kind in ("qkv", "o", "pin", "pout"):
+            return True
+        return side in ("enc", "dec") and kind in self.MIXED_EXTRA_KINDS.get(level, ())
 
     def _pack(self, device=None):
         dt = self.compute_dtype
@@ -482,72 +507,83 @@ class UNetSD_T2VBase(nn.Module):
                 raise NotImplementedError("stem conv input channels must be <= 16 or a multiple of 64")
             P["conv_in"] = (pack_small_conv3x3(conv_in.weight, self._kpad_in, dt, split=True), _f32(conv_in.bias))
 
-        def pack_res(rb: _ResBlockP):
+        def pack_res(rb: _ResBlockP, name):
             d = {}
+            on = lambda kind: split_weights(self._kind_on(name, kind))
             d["gn1"] = (_f32(rb.in_layers[0].weight), _f32(rb.in_layers[0].bias))
-            d["conv1"] = (pack_conv3x3(rb.in_layers[2].weight, dt), _f32(rb.in_layers[2].bias))
+            with on("conv1"):
+                d["conv1"] = (pack_conv3x3(rb.in_layers[2].weight, dt), _f32(rb.in_layers[2].bias))
             d["gn2"] = (_f32(rb.out_layers[0].weight), _f32(rb.out_layers[0].bias))
             b2 = _f32(rb.out_layers[3].bias)
-            if isinstance(rb.skip_connection, nn.Conv2d):
-                wsk = pack_linear(rb.skip_connection.weight)
-                # two-term skip operand [raw_hi | raw_lo]: the 1x1 weight appears twice
-                w2 = _w16_cat([pack_conv3x3(rb.out_layers[3].weight), wsk] + ([wsk] if self._asplit else []), dt)
-                b2 = (b2 + _f32(rb.skip_connection.bias)).contiguous()
-            else:
-                w2 = pack_conv3x3(rb.out_layers[3].weight, dt)
+            with on("conv2"):
+                if isinstance(rb.skip_connection, nn.Conv2d):
+                    wsk = pack_linear(rb.skip_connection.weight)
+                    # two-term skip operand [raw_hi | raw_lo]: the 1x1 weight appears twice
+                    w2 = _w16_cat([pack_conv3x3(rb.out_layers[3].weight), wsk] + ([wsk] if self._asplit else []), dt)
+                    b2 = (b2 + _f32(rb.skip_connection.bias)).contiguous()
+                else:
+                    w2 = pack_conv3x3(rb.out_layers[3].weight, dt)
             d["conv2"] = (w2, b2)
             tc = rb.temopral_conv
-            for i in (1, 2, 3, 4):
-                sq = getattr(tc, f"conv{i}")
-                d[f"tgn{i}"] = (_f32(sq[0].weight), _f32(sq[0].bias))
-                d[f"tconv{i}"] = (pack_temporal(sq[-1].weight, dt), _f32(sq[-1].bias))
+            with on("tconv"):
+                for i in (1, 2, 3, 4):
+                    sq = getattr(tc, f"conv{i}")
+                    d[f"tgn{i}"] = (_f32(sq[0].weight), _f32(sq[0].bias))
+                    d[f"tconv{i}"] = (pack_temporal(sq[-1].weight, dt), _f32(sq[-1].bias))
             return d
 
-        def pack_tblock(tb: _TBlockP, cross: bool):
+        def pack_tblock(tb: _TBlockP, cross: bool, name):
             d = {}
+            keep = lambda kind: split_weights(self._kind_on(name, kind))
             for i in (1, 2, 3):
                 n = getattr(tb, f"norm{i}")
                 d[f"ln{i}"] = (_f32(n.weight), _f32(n.bias))
             a1 = tb.attn1
-            d["qkv1"] = pack_linear(torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0), dt)
-            d["o1"] = (pack_linear(a1.to_out[0].weight, dt), _f32(a1.to_out[0].bias))
+            with keep("qkv"):
+                d["qkv1"] = pack_linear(torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0), dt)
+            with keep("o"):
+                d["o1"] = (pack_linear(a1.to_out[0].weight, dt), _f32(a1.to_out[0].bias))
             a2 = tb.attn2
-            single = self.MIXED_SINGLE_KINDS if self.precision == "mixed" else ()
-            keep = lambda kind: split_weights(_SPLIT_WEIGHTS and kind not in single)
             if cross:
                 with keep("q2"):
                     d["q2"] = pack_linear(a2.to_q.weight, dt)
             else:
-                d["qkv2"] = pack_linear(torch.cat([a2.to_q.weight, a2.to_k.weight, a2.to_v.weight], 0), dt)
-            d["o2"] = (pack_linear(a2.to_out[0].weight, dt), _f32(a2.to_out[0].bias))
+                with keep("qkv"):
+                    d["qkv2"] = pack_linear(torch.cat([a2.to_q.weight, a2.to_k.weight, a2.to_v.weight], 0), dt)
+            with keep("o"):
+                d["o2"] = (pack_linear(a2.to_out[0].weight, dt), _f32(a2.to_out[0].bias))
             with keep("ff1"):
                 d["ff1"] = pack_geglu(tb.ff.net[0].proj.weight, tb.ff.net[0].proj.bias, dt)
             with keep("ff2"):
                 d["ff2"] = (pack_linear(tb.ff.net[2].weight, dt), _f32(tb.ff.net[2].bias))
             return d
 
-        def pack_tx(m, cross):
+        def pack_tx(m, cross, name):
             d = {"gn": (_f32(m.norm.weight), _f32(m.norm.bias))}
-            d["pin"] = (pack_linear(m.proj_in.weight, dt), _f32(m.proj_in.bias))
+            with split_weights(self._kind_on(name, "pin")):
+                d["pin"] = (pack_linear(m.proj_in.weight, dt), _f32(m.proj_in.bias))
             wpo = pack_linear(m.proj_out.weight)
             if self._asplit:                      # two-term token stream [t_hi | t_lo]: the weight appears twice
                 wpo = torch.cat([wpo, wpo], 1)
-            d["pout"] = (_w16(wpo, dt), _f32(m.proj_out.bias))
-            d["tb"] = pack_tblock(m.transformer_blocks[0], cross)
+            with split_weights(self._kind_on(name, "pout")):
+                d["pout"] = (_w16(wpo, dt), _f32(m.proj_out.bias))
+            d["tb"] = pack_tblock(m.transformer_blocks[0], cross, name)
             return d
 
         for name, m in self.named_modules():
             with split_weights(self._wants_split(name)):
                 if isinstance(m, _ResBlockP):
-                    P[name] = pack_res(m)
+                    P[name] = pack_res(m, name)
                 elif isinstance(m, _SpatialTransformerP):
-                    P[name] = pack_tx(m, True)
+                    P[name] = pack_tx(m, True, name)
                 elif isinstance(m, _TemporalTransformerP):
-                    P[name] = pack_tx(m, False)
+                    P[name] = pack_tx(m, False, name)
                 elif isinstance(m, _DownP):
-                    P[name] = (pack_conv3x3(m.op.weight, dt), _f32(m.op.bias))
+                    with split_weights(self._kind_on(name, "resample")):
+                        P[name] = (pack_conv3x3(m.op.weight, dt), _f32(m.op.bias))
                 elif isinstance(m, _UpP):
-                    P[name] = (pack_conv3x3(m.conv.weight, dt), _f32(m.conv.bias))
+                    with split_weights(self._kind_on(name, "resample")):
+                        P[name] = (pack_conv3x3(m.conv.weight, dt), _f32(m.conv.bias))
             m._pname = name
         P["head_gn"] = (_f32(self.out[0].weight), _f32(self.out[0].bias))
         with split_weights(self._wants_split("out")):
