@@ -162,6 +162,11 @@ def test_mixed_precision_splits_by_resolution_level(emu_backend):
     Pa = ma.pack()
     tba = Pa[st0]["tb"]
     assert dw(tba["ff1"]) and dw(tba["ff2"]) and dw(tba["q2"]) and not dw(Pa[rb1]["conv2"]) and not dw(Pa[st1]["pin"])
+    mn = UNetSD_T2VBase(**g["cfg"], compute_dtype="fp16", precision="mixed:e0d0:noextra").eval()   # level 0 minus ff1 / ff2 / q2
+    mn.load_state_dict(sd, strict=True)
+    assert mn.MIXED_SINGLE_KINDS == ("ff1", "ff2", "q2") and mn.MIXED_EXTRA_KINDS == {} and mn.MIXED_LEVELS["dec"] == (0,)
+    Pn = mn.pack()
+    assert dw(Pn[st0]["tb"]["qkv1"]) and not dw(Pn[st0]["tb"]["ff1"]) and not dw(Pn[rb1]["conv2"]) and not dw(Pn[st1]["pin"])
     e_fast = rel_l2(m(g["x"], g["t"], y=g["y"]), g["out"])
     mh = UNetSD_T2VBase(**g["cfg"], compute_dtype="fp16", precision="high").eval()
     mh.load_state_dict(sd, strict=True)

@@ -268,11 +268,15 @@ class UNetSD_T2VBase(nn.Module):
         if self.precision.startswith("mixed:"):
             # "mixed:e0d01": two-term weights in encoder level 0 and decoder levels 0, 1 ("m3": the middle block at level 3);
             # a trailing ":all" also keeps the FeedForward / cross-attention-query weights two-term (MIXED_SINGLE_KINDS)
+            # and drops the per-kind additions of MIXED_EXTRA_KINDS (= the r03 rule); ":noextra" drops only the latter
             import re
             spec = self.precision.split(":", 1)[1]
             if spec.endswith(":all") or spec == "all":
                 self.MIXED_SINGLE_KINDS, self.MIXED_EXTRA_KINDS = (), {}
                 spec = spec[:-4] if spec.endswith(":all") else "e0d0"
+            elif spec.endswith(":noextra") or spec == "noextra":      # the level rule minus MIXED_SINGLE_KINDS only
+                self.MIXED_EXTRA_KINDS = {}                          # (the rule r04's last GPU call measured)
+                spec = spec[:-8] if spec.endswith(":noextra") else "e0d0"
             assert re.fullmatch(r"(?:[edmt]\d*)*", spec), f"precision={self.precision!r}"
             lv = {"e": (), "d": (), "m": (), "t": ()}
             for side, digits in re.findall(r"([edmt])(\d*)", spec):
