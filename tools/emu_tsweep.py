@@ -48,9 +48,13 @@ def main():
             res.setdefault(pr, {})[str(tval)] = e
             print(f"{pr} t={tval}: {e:.4e} ({time.time() - t0:.0f} s)", flush=True)
         del m
+    out_path = os.path.join(ROOT, "profiles", "r04_emu_tsweep.json")
+    if os.path.exists(out_path):                      # merge: earlier sweeps (other rules / modes) stay in the file
+        old = json.load(open(out_path))["rel_l2"]
+        res = {**old, **res}
     json.dump({"what": "emulated rel-L2 of the full-size t2v UNet (headline weights, seed 0) vs the reference's fp32 forward, one "
                        "input per timestep (input seed 9000 + t)", "rel_l2": res},
-              open(os.path.join(ROOT, "profiles", "r04_emu_tsweep.json"), "w"), indent=1)
+              open(out_path, "w"), indent=1)
 
 
 if __name__ == "__main__":
