@@ -20,3 +20,20 @@ for f in ("bench_rule_r03", "bench_rule_r04l", "bench_rule_default"):
         print(f, "FAILED", e)
 PY
 timeout 900 python -m pytest tests/test_gpu_model.py -q -m gpu -k "full_width or vcomposer or t2v_full" 2>&1 | tail -5 | tee $O/pytest_full_width.log
+# the composer trunk's cheaper rules (emulated 1.027e-3 / 9.01e-4 / 8.58e-4): error and forward time on the GPU
+timeout 600 python - <<PY 2>&1 | tee $O/vcomposer_rules.log
+import sys, time, torch
+sys.path.insert(0, "tests")
+import full_cases as fc
+g = fc.load("vcomposer")
+for pr in ("mixed", "mixed:e01d01:all", "high"):
+    m = fc.build("vcomposer", g, pr, "cuda")
+    out = fc.forward("vcomposer", m, g, "cuda")
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(3):
+        fc.forward("vcomposer", m, g, "cuda")
+    torch.cuda.synchronize()
+    print(pr, "rel-L2 %.4e" % fc.error(out, g)[0], "eager forward %.1f ms" % ((time.perf_counter() - t0) / 3 * 1e3), flush=True)
+    del m, out
+    torch.cuda.empty_cache()
+PY
