@@ -534,6 +534,37 @@ def make_trajectory(R, full):
         print("ddim_step_full", float(xt1.std()), float(x0.std()))
 
 
+def make_t2v_traj6(R):
+    """r05 (VERDICT r04 missing #4 / SURVEY §8c "per-step drift"): the FIRST SIX steps of the 50-step CFG DDIM trajectory
+    of the reference at full size — its own DiffusionDDIM (diffusion_ddim.py:208-254) driving its own UNetSD_T2VBase
+    (1411 M parameters, headline weights of unet_t2v_full.pt) in fp32 on the CPU, guidance 9, eta 0, from seeded noise:
+    12 forwards.  x_t after every step is stored whole (459 KB each), so the GPU test can report the drift of the
+    benchmarked precision mode step by step through the public ddim_sample_loop-style API."""
+    g = torch.load(os.path.join(GOLD, "unet_t2v_full.pt"), weights_only=False)
+    m = R["MODEL"].build(dict(type="UNetSD_T2VBase", **g["cfg"])).eval()
+    m.load_state_dict(torch_ref.synth_state_dict(g["shapes"], seed=g["seed"]), strict=True)
+    diff = R["DIFFUSION"].build(dict(type="DiffusionDDIM", **dict(DDIM_T2V, noise_strength=0.0)))
+    gen = torch.Generator("cpu").manual_seed(8888)                  # the engines' seed (t2v_infer.yaml:14)
+    noise = torch.randn(1, 4, 16, 32, 56, generator=gen)
+    y = torch.randn(1, 77, 1024, generator=gen)
+    y_u = torch.randn(1, 77, 1024, generator=gen)
+    steps = (1 + torch.arange(0, 1000, 20)).clamp(0, 999).flip(0)[:6]
+    xs, x0s, xt = [], [], noise.clone()
+    import time
+    with torch.no_grad():
+        for step in steps:
+            t0 = time.time()
+            t = torch.full((1,), int(step), dtype=torch.long)
+            xt, x0 = diff.ddim_sample(xt, t, m, [dict(y=y), dict(y=y_u)], guide_scale=9.0, ddim_timesteps=50, eta=0.0)
+            xs.append(xt.clone())
+            x0s.append(x0.clone())
+            print("traj6 step t=%d: x_t std %.4f, x0 std %.4f (%.0f s)" % (int(step), float(xt.std()), float(x0.std()),
+                                                                          time.time() - t0), flush=True)
+    torch.save(dict(noise_seed=8888, steps=steps, xt=torch.stack(xs), x0=torch.stack(x0s), guide_scale=9.0, ddim_timesteps=50,
+                    model_fixture="unet_t2v_full.pt", cfg=dict(DDIM_T2V, noise_strength=0.0)),
+               os.path.join(GOLD, "ddim_traj6_full.pt"))
+
+
 def make_ddpm(R):
     """The reference's ancestral sampler and closed-form q(.) helpers (diffusion_ddim.py:99-145) with the dummy model:
     three p_sample steps (CFG, t = 999 / 500 / 0), a whole 1000-step p_sample_loop, one stochastic DDIM step (eta = 0.7),
@@ -731,7 +762,7 @@ def main():
     if args.only == "i2vgen_full":
         make_i2vgen_full(R)
         return
-    extra = dict(t2v_extra=make_t2v_extra, videolcm_full=make_videolcm_full, tft2v_full=make_tft2v_full,
+    extra = dict(t2v_traj6=make_t2v_traj6, t2v_extra=make_t2v_extra, videolcm_full=make_videolcm_full, tft2v_full=make_tft2v_full,
                  sr600_full=make_sr600_full, vcomposer_full=make_vcomposer_full)
     if args.only in extra:
         extra[args.only](R)

@@ -365,6 +365,24 @@ def tapgemm_cases(dt):
     c["lin_154x4096x1024_textmlp"] = make_tapgemm(dt, 154, 4096, 1024)
     c["lin_ff2_split_out_640"] = make_tapgemm(dt, 3000, 640, 2560, out_dtype=dt, residual=True, split_out=True)
     c["lin_split_out_shortK_dual"] = make_tapgemm(dt, 9000, 320, 320, out_dtype=dt, residual=True, split_out=True)
+    c.update(panel_cases(dt))
+    return c
+
+
+def panel_cases(dt, dualw=False):
+    """r05: launches the W-panel-resident shape takes (csrc/panelgemm.hip: linear, K = 320, M >= 2048, N a multiple of the
+    panel width) — every epilogue, ragged M (last slice partial, slices not a multiple of the 8 waves or of the row
+    ranges), A / W / out / residual views with padded leading dimensions, one / several / many column panels."""
+    px = "dw_panel_" if dualw else "panel_"
+    c = {}
+    c[px + "o_proj_res_f32"] = make_tapgemm(dt, 9000, 320, 320, residual=True, dualw=dualw)
+    c[px + "f32_nores_raggedM"] = make_tapgemm(dt, 2049, 320, 320, dualw=dualw)
+    c[px + "qkv_out16"] = make_tapgemm(dt, 5003, 960, 320, out_dtype=dt, bias=False, dualw=dualw)
+    c[px + "q_out16_res"] = make_tapgemm(dt, 4100, 320, 320, out_dtype=dt, residual=True, dualw=dualw)
+    c[px + "geglu"] = make_tapgemm(dt, 4099, 2560, 320, epilogue=L.EPI_GEGLU, out_dtype=dt, dualw=dualw)
+    c[px + "geglu_res"] = make_tapgemm(dt, 2500, 640, 320, epilogue=L.EPI_GEGLU, out_dtype=dt, residual=True, dualw=dualw)
+    c[px + "views"] = make_tapgemm(dt, 3000, 320, 320, a_pad=64, w_pad=0 if dualw else 128, residual=True, dualw=dualw)
+    c[px + "wide_N"] = make_tapgemm(dt, 2100, 1600 if not dualw else 1280, 320, out_dtype=dt, dualw=dualw)
     return c
 
 
@@ -405,6 +423,7 @@ def tapgemm_dw_cases(dt):
     # two-term OUTPUT rows [hi | lo] (the FF output feeding proj_out): 160- and 128-wide column tiles, ragged M
     c["dw_ff2_split_out_320"] = make_tapgemm(dt, 4000, 320, 1280, out_dtype=dt, residual=True, split_out=True, dualw=True)
     c["dw_ff2_split_out_1280"] = make_tapgemm(dt, 900, 1280, 5120, out_dtype=dt, residual=True, split_out=True, dualw=True)
+    c.update(panel_cases(dt, dualw=True))
     return c
 
 

@@ -14,7 +14,7 @@ from vgen_amd import lib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 VGEN_E_BADARG = -1         # include/vgen_hip.h
 FAKE = 0x7f0000001000        # an aligned non-null address: the checks and the planner never dereference operands
-SHAPE_PP, SHAPE_DUAL, SHAPE_PP128 = 0, 1, 2
+SHAPE_PP, SHAPE_DUAL, SHAPE_PP128, SHAPE_PANEL = 0, 1, 2, 3
 
 
 def good_linear():
@@ -113,6 +113,14 @@ def test_plans_of_the_benchmark_launches_are_legal():
                 shape, bn, sk = out3
                 KT = taps * (C1 // 64) + C2 // 64
                 sig = (mode, M, N, C1, C2, epi, f32, dw, colstats, residual)
+                if shape == SHAPE_PANEL:
+                    # r05, csrc/panelgemm.hip: the W-panel-resident shape takes the K = 320 linears of the full-resolution
+                    # level and nothing else; 160-column panels, 80 with a two-term weight (64 under GEGLU), no split-K
+                    assert mode == lib.TAP_LINEAR and C1 == 320 and C2 == 0 and M >= 2048 and not colstats, sig
+                    assert bn == ((64 if epi else 80) if dw else 160) and N % bn == 0 and sk == 1, (sig, bn, sk)
+                    assert l.vgen_tapgemm_ws_bytes(C.byref(a)) == 0, sig
+                    seen.add((shape, bn, False))
+                    continue
                 assert shape in (SHAPE_PP, SHAPE_DUAL, SHAPE_PP128), sig
                 assert bn in (64, 128, 160) and (N % bn == 0 or bn == 64), (sig, bn)
                 assert not (epi and bn == 160), sig                      # GEGLU tiles pair 16 value with 16 gate columns
@@ -123,7 +131,7 @@ def test_plans_of_the_benchmark_launches_are_legal():
                 assert l.vgen_tapgemm_ws_bytes(C.byref(a)) == (sk * M * N * 4 if sk > 1 else 0), sig
                 seen.add((shape, bn, sk > 1))
     # the sweep exercises the planner's whole range: every shape, every tile width, split-K and no split-K
-    assert {s for s, _, _ in seen} == {SHAPE_PP, SHAPE_DUAL, SHAPE_PP128}, seen
+    assert {s for s, _, _ in seen} == {SHAPE_PP, SHAPE_DUAL, SHAPE_PP128, SHAPE_PANEL}, seen
     assert {b for _, b, _ in seen} >= {128, 160} and {k for _, _, k in seen} == {False, True}, seen
 
 

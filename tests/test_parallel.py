@@ -178,6 +178,112 @@ def test_unit_partition_world2_matches_single_process(P):
     assert all(u % 2 == 0 for u in res[0][2]) and all(u % 2 == 1 for u in res[1][2])
 
 
+def _worker_g1(rank, world, port, P, q):
+    """G = 1 (no classifier-free guidance: VideoLCM / DDIM inversion): P single-branch units over the ranks through
+    UnitPartition.run_units — the map BASELINE config 4 names (P = 8 prompts, one unit each)."""
+    import sys
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle.abi_emulator import EmuBackend
+    from vgen_amd import ops
+    from vgen_amd.parallel import UnitPartition
+    ops.set_backend(EmuBackend())
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(P, 4, 2, 4, 4, generator=g)
+    kw = [dict(y=torch.randn(P, 7, 8, generator=g))]
+    part = UnitPartition()
+    t = torch.full((P,), 759, dtype=torch.long)
+    (out,) = part.run_units(_ToyUNet(), x, t, kw)
+    q.put((rank, out.numpy(), part.my_units(P, P, 1)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _spawn(target, world, args, timeout):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args) + (q,)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = _recv(q, world, timeout)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return sorted(res, key=lambda r: r[0])
+
+
+def test_unit_partition_world4_cfg_prompts_match_single_process():
+    """r05 (VERDICT r04 missing #6): FOUR ranks, P = 4 CFG prompts (G = 2, U = 8: the 'prompt' layout — every rank owns one
+    whole cond / uncond pair, BASELINE config 2 at 4 of its 8 GPUs) and P = 6 (P % W != 0: the 'unit' layout, 12 units
+    3 per rank): one all-gather per step, every rank ends with the single-process state, exactly (fp32 toy model)."""
+    from oracle.abi_emulator import EmuBackend
+    from vgen_amd import ops
+    from vgen_amd.diffusion import DiffusionDDIM
+    for P in (4, 6):
+        res = _spawn(_worker, 4, (P,), 180)
+        prev = ops.set_backend(EmuBackend())
+        try:
+            g = torch.Generator().manual_seed(0)
+            noise = torch.randn(P, 4, 2, 4, 4, generator=g)
+            kw = [dict(y=torch.randn(P, 7, 8, generator=g)), dict(y=torch.randn(P, 7, 8, generator=g))]
+            d = DiffusionDDIM(schedule="cosine", schedule_param=dict(num_timesteps=1000, cosine_s=0.008, zero_terminal_snr=True),
+                              mean_type="v", var_type="fixed_small")
+            ref = d.ddim_sample_loop(noise.clone(), _ToyUNet(), kw, guide_scale=9.0, ddim_timesteps=10, eta=0.0)
+        finally:
+            ops.set_backend(prev)
+        for r in res[1:]:
+            assert torch.equal(r[1], res[0][1])                                          # all ranks hold the same state
+        assert torch.allclose(res[0][1], ref, atol=1e-6, rtol=1e-6)
+        assert sorted(u for r in res for u in r[2]) == list(range(2 * P))                # every unit owned exactly once
+        assert all(len(r[2]) == 2 * P // 4 for r in res)                                 # and the load is even
+
+
+def test_unit_partition_world4_single_branch_units():
+    """r05: G = 1 over FOUR ranks — P = 8 single-forward units (VideoLCM, BASELINE config 4: 8 prompts, no CFG) two per
+    rank; the gathered batch equals the unpartitioned evaluation exactly and comes back in prompt order."""
+    P = 8
+    res = _spawn(_worker_g1, 4, (P,), 180)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(P, 4, 2, 4, 4, generator=g)
+    y = torch.randn(P, 7, 8, generator=g)
+    ref = _ToyUNet()(x, torch.full((P,), 759, dtype=torch.long), y=y)
+    for r in res:
+        assert torch.allclose(r[1], ref, atol=1e-6, rtol=1e-6)
+        assert len(r[2]) == 2
+    assert sorted(u for r in res for u in r[2]) == list(range(P))
+
+
+def test_unit_maps_are_bijections_for_eight_ranks():
+    """r05: the (owner, slot) map of every configuration BASELINE.json names for ONE 8-GPU node, checked without a node —
+    config 2 / 3 (P = 4 CFG prompts: U = 8 on W = 8; P = 8: U = 16), config 4 (P = 8 LCM prompts, G = 1), the north-star's
+    P = 1 pair on W = 2, and ragged cases: unit u -> (rank, slot) is injective, slots are dense per rank, the per-rank load
+    differs by at most one unit, and in the 'prompt' layout both branches of a prompt sit on the same rank."""
+    from vgen_amd.parallel import UnitPartition
+    for W, P, G in [(8, 4, 2), (8, 8, 2), (8, 8, 1), (8, 16, 1), (2, 1, 2), (4, 4, 2), (4, 8, 1), (8, 3, 2), (8, 5, 1), (4, 6, 2)]:
+        parts = []
+        for r in range(W):
+            p = UnitPartition()
+            p.world, p.rank = W, r
+            parts.append(p)
+        U = P * G
+        seen = {}
+        for u in range(U):
+            o, sl = parts[0].owner(u, P, G), parts[0].slot(u, P, G)
+            assert 0 <= o < W and 0 <= sl < parts[0].slots(U), (W, P, G, u)
+            assert (o, sl) not in seen, (W, P, G, u, seen[(o, sl)])
+            seen[(o, sl)] = u
+        loads = [len(p.my_units(U, P, G)) for p in parts]
+        assert sum(loads) == U and max(loads) - min(loads) <= 1, (W, P, G, loads)
+        for p in parts:
+            mine = p.my_units(U, P, G)
+            assert [p.slot(u, P, G) for u in mine] == list(range(len(mine))), (W, P, G, p.rank, mine)   # dense, in slot order
+        if parts[0].layout(P, G) == "prompt":
+            for pr in range(P):
+                assert len({parts[0].owner(pr * G + g_, P, G) for g_ in range(G)}) == 1
+
+
 def test_partition_single_process_is_identity():
     from vgen_amd.parallel import UnitPartition
     p = UnitPartition()
@@ -359,12 +465,18 @@ def test_slice_kwargs_only_touches_per_prompt_keys():
     # ... unless every prompt is local (nothing to slice), or the caller declares it per-prompt
     assert _slice_kwargs(amb, torch.tensor([0, 1]), 2)["custom"] is amb["custom"]
     import vgen_amd.parallel as par
-    saved = par.PER_PROMPT_KEYS
+    keys = par.PER_PROMPT_KEYS                       # ONE set object, mutated in place: by-value importers stay current
     try:
         par.register_per_prompt_keys("custom")
+        assert par.PER_PROMPT_KEYS is keys and "custom" in keys
         assert torch.equal(_slice_kwargs(amb, idx, 2)["custom"], amb["custom"][1:2])
+        # the escape hatch for a SHARED table whose leading dim happens to equal the prompt count
+        par.register_shared_keys("custom")
+        assert "custom" not in keys
+        assert _slice_kwargs(amb, idx, 2)["custom"] is amb["custom"]
     finally:
-        par.PER_PROMPT_KEYS = saved
+        keys.discard("custom")
+        par.SHARED_KEYS.discard("custom")
 
 
 def test_session_key_sees_tensors_inside_containers():

@@ -40,7 +40,8 @@ fp, nins = isa_fingerprint(t)
 HASH_FILE = os.path.join(ROOT, "tests", "golden", "tapgemm_isa.sha256")
 print(f"ISA fingerprint: {fp} ({nins} instructions)")
 if "--update-hash" in sys.argv and not defs:
-    open(HASH_FILE, "w").write(fp + "\n")
+    cc = subprocess.run([b._hipcc(), "--version"], capture_output=True, text=True).stdout.split("\n")[0].strip()
+    open(HASH_FILE, "w").write(fp + "\nhipcc: " + cc + "\n")     # the compiler the stream belongs to (tests/test_abi.py)
     print("written to", HASH_FILE)
 vs = [int(x) for x in re.findall(r"\.vgpr_spill_count:\s+(\d+)", t)]
 ss = [int(x) for x in re.findall(r"\.sgpr_spill_count:\s+(\d+)", t)]

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libvgen_hip.so")
-SOURCES = ["cabi.cpp", "tapgemm.hip", "norms.hip", "attention.hip", "misc.hip", "stems.hip"]
+SOURCES = ["cabi.cpp", "tapgemm.hip", "panelgemm.hip", "norms.hip", "attention.hip", "misc.hip", "stems.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "tapgemm_plans.inc"),
            os.path.join(HERE, "..", "include", "vgen_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

@@ -22,6 +22,10 @@
 //                    2 MFMA 16x16x32, the softmax is in-lane + 2 shuffles, and P V uses the
 //                    K=16 MFMA (16x16x16) whose B layout again equals S^T's C/D layout.
 #include "common.h"
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "attention.hip uses gfx950-only instructions (ds_read_b64_tr_b16): build with --offload-arch=gfx950"
+#endif
 #include <stdlib.h>
 
 namespace {

@@ -1,0 +1,270 @@
+// panelgemm.hip — the W-panel-resident, barrier-free tap-GEMM shape for the short-K linears of the UNet's full-resolution
+// level (K = C = 320: q/k/v, the attention out-projections, proj_in, the GEGLU up-projection of every Spatial- /
+// TemporalTransformer at 32 x 56 — util.py:224-228, 337, 710, 1213 —; r05, VERDICT r04 "next" #1).
+//
+// Why another shape.  A K = 320 launch on the streaming shapes of tapgemm.hip is 5-10 K-steps per tile: the tile's fixed
+// cost (operand prologue, two barriers per K-step, an epilogue that overlaps nothing inside its block) is ~9 K-steps'
+// worth of time, i.e. most of the launch (2-3 x the floor on every level-0 linear).  Here nothing of that is left:
+//   * one block per CU, persistent.  It owns ONE panel of 160 weight rows (all of K: 100 KiB) and stages it into LDS ONCE
+//     (LDS-DMA, same bank swizzle as tapgemm.hip's stages); the 8 waves only READ it afterwards, so the main loop has no
+//     s_barrier and no LDS write at all.
+//   * the activation operand never touches LDS: every wave loads the A fragments of its own 32-row slice straight from
+//     global memory into MFMA layout (lane (lr, lq) = row lr, k = 32 ks + 8 lq ... + 7 is one 16-byte load; the 4 lanes of
+//     a row read 64 contiguous bytes) — 80 VGPRs for the whole K extent — and multiplies it against the resident panel:
+//     200 MFMAs per slice, one ds_read_b128 of W per TWO MFMAs (128 B/clk of the LDS's 256).
+//   * waves are independent: wave w walks slices w, w + 8, ... of the block's row range; its A loads for the next slice are
+//     issued before its epilogue, and the partner wave on the same SIMD multiplies while it loads / converts / stores —
+//     the overlap the "dual" shape buys with a second block, without a second copy of the weights.
+//   * dual-W (vgen_tapgemm_args.dualw): the panel is 80 output columns, LDS rows 0-79 = W_hi, 80-159 = W_lo, both
+//     accumulate into the same 80-column accumulators; A is loaded and held once.  (GEGLU + dual-W: 64 columns.)
+//   * blocks of one row range (all column panels) sit on the same XCD (block b -> XCD b % 8 renumbering), so the A rows
+//     every panel re-reads come out of that XCD's L2: HBM sees A once.
+// Same operand swap and C/D layout as tapgemm.hip (D[n][m]: a lane holds 4 consecutive n of one row m), same epilogue
+// arithmetic order (bias, then residual through the accumulator's initial value; GEGLU gate polynomial; paired 16-byte
+// 16-bit stores) — results differ from the streaming shapes by fp32 summation order only.
+#include "common.h"
+
+#include <type_traits>
+
+namespace {
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+__device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+constexpr int PANEL_WAVES = 8;
+constexpr int SLICE_ROWS = 32;
+
+enum { EPI_F32 = 0, EPI_16 = 1, EPI_GEGLU16 = 2 };   // fp32 store | 16-bit store | GEGLU gate + 16-bit store
+
+template <typename T, int KS, int BN, bool DW, int EPI>
+__global__ __launch_bounds__(PANEL_WAVES * 64) void panel_kernel(const vgen_tapgemm_args p, const int P, const int Cn) {
+  constexpr int KT = KS / 2;                  // 64-element K-tiles of the LDS panel
+  constexpr int LROWS = DW ? 2 * BN : BN;     // LDS rows: [W_hi rows | W_lo rows] with dual-W
+  constexpr int NFL = LROWS / 16;             // W fragments per 32-element k-step
+  constexpr int NF = BN / 16;                 // accumulator column fragments
+  constexpr int MF = SLICE_ROWS / 16;         // accumulator row fragments (2)
+  constexpr int TILE_BYTES = LROWS * 128;
+  constexpr int W_BYTES = KT * TILE_BYTES;
+  static_assert(KS % 2 == 0 && LROWS % 16 == 0 && BN % 16 == 0, "panel geometry");
+
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* const bias_lds = (float*)(smem + W_BYTES);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15;   // row within a 16-row fragment
+  const int lq = lane >> 4;   // k-chunk (operands) / 4-column group (C/D)
+
+  // logical block id: XCD b % 8 gets a contiguous run (all panels of a row range share one L2)
+  unsigned L;
+  {
+    const unsigned nwg = gridDim.x, bid = blockIdx.x;
+    const unsigned xcd = bid & 7u, q = nwg >> 3, r = nwg & 7u;
+    L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int panel = (int)(L % (unsigned)P);
+  const int chunk = (int)(L / (unsigned)P);
+  const int n0 = panel * BN;
+  const int M = (int)p.M;                                   // < 2^31 (host check)
+  const int nslices = (M + SLICE_ROWS - 1) / SLICE_ROWS;
+  const int s_begin = (int)(((int64_t)nslices * chunk) / Cn);
+  const int s_end = (int)(((int64_t)nslices * (chunk + 1)) / Cn);
+
+  const uint16_t* __restrict__ A = (const uint16_t*)p.A;
+  const uint16_t* __restrict__ W = (const uint16_t*)p.W;
+  const int64_t ldw = p.ldw ? p.ldw : (int64_t)KS * 32 * (DW ? 2 : 1);
+
+  // ---- A fragments of one 32-row slice: straight from global memory into MFMA layout ----------------------------
+  u32x4 xa[MF][KS];
+  auto load_a = [&](int s) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mi = 0; mi < MF; ++mi) {
+      int row = s * SLICE_ROWS + mi * 16 + lr;
+      row = row < M ? row : M - 1;                           // tail rows re-read the last row; never stored
+      const uint16_t* ap = A + (int64_t)row * p.lda + lq * 8;
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk) xa[mi][kk] = *(const u32x4*)(ap + kk * 32);
+    }
+  };
+  int s = s_begin + wave;
+  if (s < s_end) load_a(s);                                  // in flight while the panel is staged
+
+  // ---- stage the W panel: KT tiles of [LROWS][64] 16-bit, chunk c of row r at ((c ^ (r & 7)) << 4) ---------------
+  {
+    const int rsub = lane >> 3, c = lane & 7;
+    constexpr int R8 = LROWS / 8;                            // 8-row groups (one 1-KiB DMA instruction each) per tile
+    for (int i = wave; i < KT * R8; i += PANEL_WAVES) {
+      const int kt = i / R8, r8 = i - kt * R8;
+      const int lrow = r8 * 8 + rsub;
+      const int lo = DW ? (lrow >= BN ? 1 : 0) : 0;
+      const int n = n0 + lrow - lo * BN;
+      const uint16_t* src = W + (int64_t)n * ldw + (DW ? (kt * 2 + lo) * 64 : kt * 64) + ((c ^ rsub) << 3);
+      glds16(src, smem + kt * TILE_BYTES + r8 * 1024);
+    }
+    if (tid < BN) bias_lds[tid] = p.bias ? p.bias[n0 + tid] : 0.f;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const unsigned char* const wrd = smem + lr * 128;          // this lane's row inside a 16-row fragment
+  const int sw = lr & 7;
+  const bool res_folded = EPI != EPI_GEGLU16 && p.residual != nullptr;     // GEGLU adds its residual after the gate
+
+  for (; s < s_end; s += PANEL_WAVES) {
+    const int mrow0 = s * SLICE_ROWS;
+    f32x4 acc[NF][MF];
+    // accumulators start from the fp32 residual tile (same as tapgemm.hip: the loads land while the A fragments do); tail
+    // rows / columns re-read a valid address and are never stored, so the loads need no per-lane predicate
+    if (res_folded) {
+#pragma unroll
+      for (int mi = 0; mi < MF; ++mi) {
+        int m = mrow0 + mi * 16 + lr;
+        m = m < M ? m : M - 1;
+        const float* const rp = p.residual + (int64_t)m * p.ldr + n0 + lq * 4;
+#pragma unroll
+        for (int ni = 0; ni < NF; ++ni) acc[ni][mi] = *(const f32x4*)(rp + ni * 16);
+      }
+    } else {
+#pragma unroll
+      for (int mi = 0; mi < MF; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NF; ++ni) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    // ---- KS * NFL W fragments against the resident panel, two MFMAs each; the fragment reads run RING fragments ahead
+    // of their MFMAs (left to itself hipcc serialises read -> lgkmcnt(0) -> 2 MFMAs through ONE fragment register) -------
+    constexpr int NT = KS * NFL;
+    constexpr int RING = NF >= 10 ? 4 : 6;                    // 16 / 24 VGPRs of fragments in flight (the 160-column panel has no more to spare)
+    u32x4 wring[RING];
+    auto wread = [&](int t) __attribute__((always_inline)) -> u32x4 {
+      const int kk = t / NFL, nfl = t % NFL;
+      return *(const u32x4*)(wrd + (kk >> 1) * TILE_BYTES + ((((kk & 1) * 4 + lq) ^ sw) << 4) + nfl * 16 * 128);
+    };
+#pragma unroll
+    for (int t = 0; t < RING; ++t) wring[t] = wread(t);
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      const int kk = t / NFL, nfl = t % NFL;
+      const int ni = DW ? nfl % NF : nfl;
+      const u32x4 wv = wring[t % RING];
+#pragma unroll
+      for (int mi = 0; mi < MF; ++mi) acc[ni][mi] = T::mfma32(wv, xa[mi][kk], acc[ni][mi]);
+      if (t + RING < NT) wring[t % RING] = wread(t + RING);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the A registers are dead: the next slice's loads fly while this slice's epilogue converts and stores
+    if (s + PANEL_WAVES < s_end) load_a(s + PANEL_WAVES);
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue (N % BN == 0 is an eligibility condition: no column guards) -------------------------------------
+    auto bias4 = [&](int ni) __attribute__((always_inline)) -> f32x4 { return *(const f32x4*)(bias_lds + ni * 16 + lq * 4); };
+    // two column fragments -> one 16-byte store per lane (v_permlane16_swap, see tapgemm.hip's 16-bit epilogue)
+    auto store_pair16 = [&](uint16_t* dst, const f32x4& va, const f32x4& vb) __attribute__((always_inline)) {
+      const u32x2 pa = pack4<T>(va.x, va.y, va.z, va.w);
+      const u32x2 pb = pack4<T>(vb.x, vb.y, vb.z, vb.w);
+      const auto sx = __builtin_amdgcn_permlane16_swap(pa.x, pb.x, false, false);
+      const auto sy = __builtin_amdgcn_permlane16_swap(pa.y, pb.y, false, false);
+      const u32x4 q = {sx[0], sy[0], sx[1], sy[1]};
+      *(u32x4*)(dst + (lq & 1) * 16 + (lq >> 1) * 8) = q;
+    };
+#pragma unroll
+    for (int mi = 0; mi < MF; ++mi) {
+      const int64_t m = mrow0 + mi * 16 + lr;
+      if (m >= M) continue;
+      if constexpr (EPI == EPI_F32) {
+        float* const orow = (float*)p.out + m * p.ldo + n0 + lq * 4;
+#pragma unroll
+        for (int ni = 0; ni < NF; ++ni) *(f32x4*)(orow + ni * 16) = acc[ni][mi] + bias4(ni);
+      } else if constexpr (EPI == EPI_16) {
+        uint16_t* const orow = (uint16_t*)p.out + m * p.ldo + n0;
+#pragma unroll
+        for (int ni = 0; ni + 1 < NF; ni += 2)
+          store_pair16(orow + ni * 16, acc[ni][mi] + bias4(ni), acc[ni + 1][mi] + bias4(ni + 1));
+        if constexpr (NF % 2 == 1) {
+          const f32x4 v = acc[NF - 1][mi] + bias4(NF - 1);
+          *(u32x2*)(orow + (NF - 1) * 16 + lq * 4) = pack4<T>(v.x, v.y, v.z, v.w);
+        }
+      } else {
+        // packed columns [16 value | 16 gate]: fragment pairs (2 np, 2 np + 1) -> 16 output columns n0 / 2 + 16 np ...
+        static_assert(EPI != EPI_GEGLU16 || NF % 2 == 0, "GEGLU pairs value / gate fragments");
+        constexpr int NP = NF / 2;
+        uint16_t* const orow = (uint16_t*)p.out + m * p.ldo + n0 / 2;
+        const float* const rrow = p.residual ? p.residual + m * p.ldr + n0 / 2 + lq * 4 : nullptr;
+        auto gated = [&](int np) __attribute__((always_inline)) -> f32x4 {
+          f32x4 o = geglu4(acc[2 * np][mi] + bias4(2 * np), acc[2 * np + 1][mi] + bias4(2 * np + 1));
+          if (rrow) o += *(const f32x4*)(rrow + np * 16);
+          return o;
+        };
+#pragma unroll
+        for (int np = 0; np + 1 < NP; np += 2) store_pair16(orow + np * 16, gated(np), gated(np + 1));
+        if constexpr (NP % 2 == 1) {
+          const f32x4 o = gated(NP - 1);
+          *(u32x2*)(orow + (NP - 1) * 16 + lq * 4) = pack4<T>(o.x, o.y, o.z, o.w);
+        }
+      }
+    }
+  }
+}
+
+template <typename T, int KS, int BN, bool DW, int EPI>
+int launch_panel(const vgen_tapgemm_args& a, hipStream_t stream) {
+  constexpr int LROWS = DW ? 2 * BN : BN;
+  constexpr size_t lds = (size_t)(KS / 2) * LROWS * 128 + BN * sizeof(float);
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute((const void*)panel_kernel<T, KS, BN, DW, EPI>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) {
+      vgen_set_error("tapgemm(panel): hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
+      return (int)e;
+    }
+    attr_done = true;
+  }
+  const int P = a.N / BN;
+  int Cn = 256 / P;                                          // one block per CU: row ranges x panels <= 256
+  const int nslices = (int)((a.M + SLICE_ROWS - 1) / SLICE_ROWS);
+  if (Cn > nslices) Cn = nslices;
+  if (Cn < 1) Cn = 1;
+  hipLaunchKernelGGL((panel_kernel<T, KS, BN, DW, EPI>), dim3((unsigned)(P * Cn)), dim3(PANEL_WAVES * 64), lds, stream, a, P,
+                     Cn);
+  return vgen_check_launch("tapgemm(panel)");
+}
+
+}  // namespace
+
+// which launches take the panel shape (host side; tapgemm.hip's dispatch asks before it plans a streaming shape):
+// the column-panel width, 0 = not this shape
+int vgen_panel_bn(const vgen_tapgemm_args& a) {
+  const bool geglu = a.epilogue == VGEN_EPI_GEGLU;
+  if (a.mode != VGEN_TAP_LINEAR || a.taps != 1 || a.C2 != 0 || a.C1 != 320) return 0;
+  if (a.rowbias || a.colstats || a.split_out) return 0;
+  if (a.M < 2048) return 0;                                  // a handful of slices per CU: the streaming shapes' split-K wins
+  if (a.out_dtype == VGEN_F32 ? (a.ldo % 4 != 0 || geglu) : (a.ldo % 8 != 0)) return 0;
+  if (a.residual && a.ldr % 4 != 0) return 0;
+  const int bn = a.dualw ? (geglu ? 64 : 80) : 160;
+  return a.N % bn == 0 ? bn : 0;
+}
+
+template <typename T>
+static int panel_dispatch(const vgen_tapgemm_args& a, hipStream_t s) {
+  const int bn = vgen_panel_bn(a);
+  const int epi = a.epilogue == VGEN_EPI_GEGLU ? EPI_GEGLU16 : (a.out_dtype == VGEN_F32 ? EPI_F32 : EPI_16);
+  if (bn == 160 && epi == EPI_F32) return launch_panel<T, 10, 160, false, EPI_F32>(a, s);
+  if (bn == 160 && epi == EPI_16) return launch_panel<T, 10, 160, false, EPI_16>(a, s);
+  if (bn == 160 && epi == EPI_GEGLU16) return launch_panel<T, 10, 160, false, EPI_GEGLU16>(a, s);
+  if (bn == 80 && epi == EPI_F32) return launch_panel<T, 10, 80, true, EPI_F32>(a, s);
+  if (bn == 80 && epi == EPI_16) return launch_panel<T, 10, 80, true, EPI_16>(a, s);
+  if (bn == 64 && epi == EPI_GEGLU16) return launch_panel<T, 10, 64, true, EPI_GEGLU16>(a, s);
+  vgen_set_error("tapgemm(panel): launch not eligible");
+  return VGEN_E_BADARG;
+}
+
+int vgen_panel_launch(const vgen_tapgemm_args& a, hipStream_t s) {
+  return a.dtype == VGEN_BF16 ? panel_dispatch<BF16>(a, s) : panel_dispatch<F16>(a, s);
+}

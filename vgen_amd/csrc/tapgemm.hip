@@ -40,6 +40,11 @@
 #include <stdlib.h>
 #include <type_traits>
 
+// panelgemm.hip: the W-panel-resident shape of the short-K (K = 320) linears; vgen_panel_bn() = its column-panel width for
+// a launch it takes, 0 for every other launch
+int vgen_panel_bn(const vgen_tapgemm_args& a);
+int vgen_panel_launch(const vgen_tapgemm_args& a, hipStream_t s);
+
 namespace {
 
 // Two block shapes of ONE kernel template (BM x BN tile, BK K-elements per stage, WM x WN waves):
@@ -894,7 +899,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vgen_tapgemm_a
 // small cost model (microseconds; constants fitted to profiles/r01_*_tapgemm_shapes.json):
 //   cost = rounds(tiles * s / slots) * (ceil(KT / s) * t_ktile + t_tile) + [s > 1] * reduce(s)
 // with KT in 64-element K-steps, slots = 256 ("pp", one block per CU) or 512 ("dual").
-enum Shape { SHAPE_PP = 0, SHAPE_DUAL = 1, SHAPE_PP128 = 2 };
+enum Shape { SHAPE_PP = 0, SHAPE_DUAL = 1, SHAPE_PP128 = 2, SHAPE_PANEL = 3 };
 // r04: 224-row tiles (every row count of the t2v UNet is 7 * 2^k, so 256-row tiles fill the last round over the CUs at
 // most 87.5 %) were built as a dual 224 x BN shape and a 224 x 320 ping-pong shape, passed every parity case they are legal
 // for, and measured +0.5 % (mixed) / +1.4 % (single-pass) SLOWER on the whole step in a same-box A/B
@@ -1066,8 +1071,18 @@ int launch(const vgen_tapgemm_args& a, int splitk, hipStream_t stream) {
   return vgen_check_launch("tapgemm(splitk reduce)");
 }
 
+// the panel shape is asked first: a launch it takes is never planned on a streaming shape (tuning build:
+// VGEN_TAPGEMM_PANEL=0 sends everything to the streaming shapes — the same-box A/B of the two)
+int panel_bn(const vgen_tapgemm_args& a) {
+#ifdef VGEN_TUNING
+  if (env_int("VGEN_TAPGEMM_PANEL", 1) == 0) return 0;
+#endif
+  return vgen_panel_bn(a);
+}
+
 template <typename T>
 int dispatch(const vgen_tapgemm_args& a, hipStream_t s) {
+  if (panel_bn(a)) return vgen_panel_launch(a, s);
   const Plan pl = make_plan(a);
   if (a.dualw) {
     if (pl.shape == SHAPE_PP128) {
@@ -1108,6 +1123,12 @@ int dispatch(const vgen_tapgemm_args& a, hipStream_t s) {
 
 extern "C" int vgen_tapgemm_query_plan(const vgen_tapgemm_args* args, int32_t* out3) {
   if (!args || !out3 || args->N <= 0 || args->M <= 0 || args->C1 <= 0 || args->C1 % 64 || args->C2 % 64) return VGEN_E_BADARG;
+  if (const int bn = panel_bn(*args)) {
+    out3[0] = SHAPE_PANEL;
+    out3[1] = bn;
+    out3[2] = 1;
+    return 0;
+  }
   const Plan pl = make_plan(*args);
   out3[0] = pl.shape;
   out3[1] = pl.bn;
@@ -1138,6 +1159,7 @@ extern "C" int vgen_tapgemm_set_plans(const int64_t* rows, int32_t n) {
 
 extern "C" size_t vgen_tapgemm_ws_bytes(const vgen_tapgemm_args* args) {
   if (!args || args->N <= 0 || args->M <= 0 || args->C1 <= 0 || args->C1 % 64 || args->C2 % 64) return 0;
+  if (panel_bn(*args)) return 0;
   const int s = make_plan(*args).splitk;
   return s > 1 ? (size_t)s * args->M * args->N * sizeof(float) : 0;
 }

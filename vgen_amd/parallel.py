@@ -34,15 +34,24 @@ _FORCE_COLLECTIVE = os.environ.get("VGEN_FORCE_COLLECTIVE") == "1"
 # kwargs of the reference's UNets that are batched over the prompts (dim 0 = batch): y / fps / image / local_image of
 # UNetSD_T2VBase / I2VGen (unet_t2v.py:210-223, unet_i2vgen.py:243-262) and the composer conditions of VideoLCM / TFT2V
 # (unet_videolcm.py:541-560).  Everything else (config objects, flags, shared tensors) is passed through.
-PER_PROMPT_KEYS = frozenset({
+# ONE shared set object, mutated in place: `from vgen_amd.parallel import PER_PROMPT_KEYS` stays current
+PER_PROMPT_KEYS = {
     "y", "fps", "image", "local_image", "depth", "sketch", "canny", "masked", "motion", "single_sketch", "histogram",
-    "video_mask", "focus_present_mask", "x_lr", "zero_y", "y_words", "t_w"})
+    "video_mask", "focus_present_mask", "x_lr", "zero_y", "y_words", "t_w"}
+SHARED_KEYS = set()        # tensor kwargs declared SHARED by all prompts even when their leading dim happens to equal P
 
 
 def register_per_prompt_keys(*names):
     """Custom models: declare further kwargs that are batched over the prompts (sliced per rank like `y`)."""
-    global PER_PROMPT_KEYS
-    PER_PROMPT_KEYS = PER_PROMPT_KEYS | frozenset(names)
+    PER_PROMPT_KEYS.update(names)
+    SHARED_KEYS.difference_update(names)
+
+
+def register_shared_keys(*names):
+    """Custom models: declare tensor kwargs every prompt shares (passed through unsliced) — the escape hatch for a table
+    whose leading dimension happens to equal the number of prompts, which _slice_kwargs otherwise refuses to guess about."""
+    SHARED_KEYS.update(names)
+    PER_PROMPT_KEYS.difference_update(names)
 
 
 def _slice_kwargs(kw, ps, P):
@@ -54,10 +63,11 @@ def _slice_kwargs(kw, ps, P):
     register_per_prompt_keys() declares it per-prompt; reshape it or pass it under a registered name otherwise."""
     out = {}
     for k, v in kw.items():
-        if k not in PER_PROMPT_KEYS and torch.is_tensor(v) and v.dim() >= 1 and P > 1 and v.shape[0] == P and len(ps) != P:
+        if k not in PER_PROMPT_KEYS and k not in SHARED_KEYS and torch.is_tensor(v) and v.dim() >= 1 and P > 1 and v.shape[0] == P and len(ps) != P:
             raise ValueError(f"kwarg {k!r}: tensor with leading dim == prompt count {P} under a name that is not in "
                              f"PER_PROMPT_KEYS — cannot tell a per-prompt batch from a shared tensor; call "
-                             f"vgen_amd.parallel.register_per_prompt_keys({k!r}) if it is batched over the prompts")
+                             f"vgen_amd.parallel.register_per_prompt_keys({k!r}) if it is batched over the prompts, "
+                             f"register_shared_keys({k!r}) if every prompt shares it")
         if k in PER_PROMPT_KEYS and torch.is_tensor(v) and v.dim() >= 1:
             if v.shape[0] == P:
                 out[k] = v[ps]

@@ -155,9 +155,12 @@ class UnitSession:
             if per_frame != self.per_frame or ctx.shape[1] != self.Lctx or shared != self.shared or \
                     (fps is None) != (self.fps is None):
                 return False
+        # everything that can fail (allocations, the K/V GEMM) runs BEFORE the first write into a buffer a graph reads
+        kv = model._context_kv(ctx.contiguous(), dev) if nU else None   # prompt constant: once per prompt
+        if not first and kv is not None and kv.shape != self.kv.shape:
+            return False
         if extra is not None:
             self.x_units[:, self.C_lat:] = extra.to(dev).float()[idx]
-        kv = model._context_kv(ctx.contiguous(), dev) if nU else None   # prompt constant: once per prompt
         if first:
             self.kv, self.fps = kv, fps
             self.per_frame, self.Lctx, self.shared = per_frame, ctx.shape[1], shared
@@ -295,7 +298,18 @@ class SessionCache:
             skey = base + (_kw_struct(kwargs_list),)
             if len(self._items) >= self.capacity and _REBIND_ON:
                 for old in list(self._items):                   # insertion order = least recently used first
-                    if self._struct.get(old) == skey and self._items[old]._bind(kwargs_list):
+                    if self._struct.get(old) != skey:
+                        continue
+                    try:
+                        ok = self._items[old]._bind(kwargs_list)
+                    except Exception:
+                        # _bind rewrites buffers the captured graphs read: a failure midway (OOM in the K/V GEMM, a shape
+                        # mismatch in a copy) must not leave a half-rebound session filed under the OLD prompt's key
+                        #  — the entry is dropped
+                        self._items.pop(old, None)
+                        self._struct.pop(old, None)
+                        raise
+                    if ok:
                         s = self._items.pop(old)
                         self._struct.pop(old, None)
                         self.rebinds += 1

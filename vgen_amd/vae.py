@@ -177,7 +177,8 @@ class AutoencoderKL(nn.Module):
         assert self.precision in ("fast", "high")
         self._packed = None
         self._attn_qb = None          # query-block override of the mid attention (tests force several blocks)
-        self._graphs = {}             # (kind, input shape, device) -> captured launch sequence of a decode / encode chunk
+        self._graphs = collections.OrderedDict()   # (kind, input shape, device) -> captured launch sequence of a chunk (LRU)
+        self._graph_pool = None       # ONE memory pool for all of this model's chunk graphs (as UnitSession does)
         if pretrained is not None:
             self.init_from_ckpt(pretrained, ignore_keys=ignore_keys)
 
@@ -200,7 +201,30 @@ class AutoencoderKL(nn.Module):
 
     def invalidate(self):
         self._packed = None
-        self._graphs = {}
+        self.clear_graphs()
+
+    def clear_graphs(self):
+        """Drop every captured chunk graph together with the memory pool they share (a chunk's peak activations stay
+        reserved while its graph lives: several GB for 720p chunks).  The engines call this between the stages of a
+        pipeline; weight loads / device moves do it themselves."""
+        self._graphs = collections.OrderedDict()
+        self._graph_pool = None
+
+    # captured graphs are per-process device objects: a copy / pickle of the model starts without them (ADVICE r04:
+    # CUDAGraph is neither picklable nor deep-copyable)
+    def __getstate__(self):
+        st = dict(self.__dict__)
+        st["_graphs"] = collections.OrderedDict()
+        st["_graph_pool"] = None
+        return st
+
+    def __deepcopy__(self, memo):
+        import copy
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__getstate__().items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        return new
 
     # -- r04: a decode / encode chunk is ONE hipGraph replay ------------------------------------------------------
     _GRAPH_SHAPES = 4             # captured input shapes kept per model (each holds a chunk's peak activations)
@@ -219,17 +243,20 @@ class AutoencoderKL(nn.Module):
         st = self._graphs.get(key)
         if st is None:
             while len(self._graphs) >= self._GRAPH_SHAPES:
-                self._graphs.pop(next(iter(self._graphs)))
+                self._graphs.popitem(last=False)        # least recently USED shape (hits move to the end below)
             self._graphs[key] = {"calls": 1}
             return rows_fn(x)
+        self._graphs.move_to_end(key)
         if "graph" not in st:
             if st.get("failed"):
                 return rows_fn(x)
             xin = x.float().contiguous().clone()
             torch.cuda.synchronize(x.device)
             g = torch.cuda.CUDAGraph()
+            if self._graph_pool is None:
+                self._graph_pool = torch.cuda.graph_pool_handle()
             try:
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                with torch.cuda.graph(g, pool=self._graph_pool, capture_error_mode="thread_local"):
                     out = rows_fn(xin)
             except Exception as ex:             # noqa: BLE001 — capture is an optimisation: stay correct, say so
                 import warnings
