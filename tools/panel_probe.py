@@ -78,6 +78,9 @@ def main():
     ]
     rows = []
     be = ops.backend()
+    only = [a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--only=")]
+    if only:
+        shapes = [sh for sh in shapes if any(o in sh[0] for o in only)]
     for name, s in shapes:
         s = dict(s)
         m = s.pop("M", M)
@@ -88,25 +91,42 @@ def main():
         outs = [torch.empty((m, n_out), dtype=specs[0].out_dtype, device=DEV) for _ in range(rot)]
         res = {"shape": name}
         ref = {}
-        for mode in ("0", "1"):
+        for mode in (("1",) if "--panel-only" in sys.argv else ("0", "1")):
             os.environ["VGEN_TAPGEMM_PANEL"] = mode
             pl = "panel" if mode == "1" else "stream"
             res[pl + "_hot_us"] = round(timeit(specs[:1], outs[:1], 30), 2)
             res[pl + "_rot_us"] = round(timeit(specs, outs, 5 * rot), 2)
             specs[0].out = None
             ref[pl] = be.tapgemm(specs[0]).float()
-        d = (ref["panel"] - ref["stream"]).norm() / ref["stream"].norm()
-        res["panel_vs_stream_rel_l2"] = float(d)
-        res["finite"] = bool(torch.isfinite(ref["panel"]).all())
         fl = 2.0 * m * specs[0].N * 320
         res["panel_TFLOPs_rot"] = round(fl / res["panel_rot_us"] / 1e6, 1)
-        res["stream_TFLOPs_rot"] = round(fl / res["stream_rot_us"] / 1e6, 1)
+        res["finite"] = bool(torch.isfinite(ref["panel"]).all())
+        if "stream" in ref:
+            d = (ref["panel"] - ref["stream"]).norm() / ref["stream"].norm()
+            res["panel_vs_stream_rel_l2"] = float(d)
+            res["stream_TFLOPs_rot"] = round(fl / res["stream_rot_us"] / 1e6, 1)
+        if "--stamps" in sys.argv:
+            # per-wave s_memtime sums per segment of the slice loop (tuning build, csrc/panelgemm.hip PANEL_STAMP)
+            os.environ["VGEN_TAPGEMM_PANEL"] = "1"
+            st = torch.zeros(4096 * 8, dtype=torch.int64, device=DEV)
+            specs[0].out, specs[0].ws = outs[0], st
+            be.tapgemm(specs[0])
+            torch.cuda.synchronize()
+            specs[0].ws = None
+            v = st.view(-1, 8).cpu().double()
+            v = v[v[:, 5] > 0]
+            names = ["residual_issue", "wait_all_landed", "mfma_loop", "next_A_issue", "epilogue"]
+            per_slice = (v[:, :5].sum(0) / v[:, 5].sum()).tolist()
+            res["stamp_cycles_per_slice"] = {n: round(c) for n, c in zip(names, per_slice)}
+            res["stamp_slices_per_wave_max"] = int(v[:, 5].max())
+            res["stamp_wave_total_cycles_max_mean"] = [round(float(v[:, :5].sum(1).max())), round(float(v[:, :5].sum(1).mean()))]
         rows.append(res)
         print(json.dumps(res), flush=True)
         del specs, outs, ref
         torch.cuda.empty_cache()
-    if len(sys.argv) > 1:
-        json.dump(rows, open(sys.argv[1], "w"), indent=1)
+    outp = [a for a in sys.argv[1:] if not a.startswith("--")]
+    if outp:
+        json.dump(rows, open(outp[0], "w"), indent=1)
 
 
 if __name__ == "__main__":

@@ -35,6 +35,21 @@ __device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_
   __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)lds_wave_base, 16, 0, 0);
 }
 
+// Tuning build only (-DVGEN_TUNING): when the launch carries a workspace pointer, every wave sums s_memtime differences
+// per segment of its slice loop into it ([block * 8 + wave][8] int64: issue of the residual loads | wait until every
+// outstanding load / store has landed | the MFMA loop | issue of the next slice's A loads | epilogue | slices) —
+// tools/panel_probe.py --stamps.  The product build has neither the parameter's use nor the waits it adds.
+#ifdef VGEN_TUNING
+#define PANEL_STAMP(i)                                              \
+  if (stamps) {                                                     \
+    const long long now_ = (long long)__builtin_amdgcn_s_memtime(); \
+    seg[i] += now_ - tprev;                                         \
+    tprev = now_;                                                   \
+  }
+#else
+#define PANEL_STAMP(i)
+#endif
+
 constexpr int PANEL_WAVES = 8;
 constexpr int SLICE_ROWS = 32;
 
@@ -115,6 +130,11 @@ __global__ __launch_bounds__(PANEL_WAVES * 64) void panel_kernel(const vgen_tapg
   const int sw = lr & 7;
   const bool res_folded = EPI != EPI_GEGLU16 && p.residual != nullptr;     // GEGLU adds its residual after the gate
 
+#ifdef VGEN_TUNING
+  long long* const stamps = (long long*)p.ws;
+  long long seg[6] = {0, 0, 0, 0, 0, 0};
+  long long tprev = stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
+#endif
   for (; s < s_end; s += PANEL_WAVES) {
     const int mrow0 = s * SLICE_ROWS;
     f32x4 acc[NF][MF];
@@ -136,6 +156,11 @@ __global__ __launch_bounds__(PANEL_WAVES * 64) void panel_kernel(const vgen_tapg
         for (int ni = 0; ni < NF; ++ni) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
 
+    PANEL_STAMP(0)
+#ifdef VGEN_TUNING
+    if (stamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    PANEL_STAMP(1)
     // ---- KS * NFL W fragments against the resident panel, two MFMAs each; the fragment reads run RING fragments ahead
     // of their MFMAs (left to itself hipcc serialises read -> lgkmcnt(0) -> 2 MFMAs through ONE fragment register) -------
     constexpr int NT = KS * NFL;
@@ -158,9 +183,11 @@ __global__ __launch_bounds__(PANEL_WAVES * 64) void panel_kernel(const vgen_tapg
       __builtin_amdgcn_sched_barrier(0);
     }
     __builtin_amdgcn_sched_barrier(0);
+    PANEL_STAMP(2)
     // the A registers are dead: the next slice's loads fly while this slice's epilogue converts and stores
     if (s + PANEL_WAVES < s_end) load_a(s + PANEL_WAVES);
     __builtin_amdgcn_sched_barrier(0);
+    PANEL_STAMP(3)
 
     // ---- epilogue (N % BN == 0 is an eligibility condition: no column guards) -------------------------------------
     auto bias4 = [&](int ni) __attribute__((always_inline)) -> f32x4 { return *(const f32x4*)(bias_lds + ni * 16 + lq * 4); };
@@ -209,7 +236,17 @@ __global__ __launch_bounds__(PANEL_WAVES * 64) void panel_kernel(const vgen_tapg
         }
       }
     }
+    PANEL_STAMP(4)
+#ifdef VGEN_TUNING
+    seg[5] += 1;
+#endif
   }
+#ifdef VGEN_TUNING
+  if (stamps && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < 6; ++i) stamps[((int64_t)blockIdx.x * PANEL_WAVES + wave) * 8 + i] = seg[i];
+  }
+#endif
 }
 
 template <typename T, int KS, int BN, bool DW, int EPI>

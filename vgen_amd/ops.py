@@ -80,6 +80,7 @@ class TapGemm:
     colstats: bool = False                    # also emit per-64-row-slab column (sum, sumsq) of the fp32 output;
                                               # attached to the returned tensor as `.vgen_cs` for groupnorm()
     split_out: bool = False                   # 16-bit output as two-term rows [hi | lo], [M, 2 N] (vgen_tapgemm_args.split_out)
+    ws: Optional[torch.Tensor] = None         # caller-provided workspace (else allocated when the plan asks for one)
     alg_k: int = 0                            # bookkeeping only: the product's K when operand rows carry two-term duplicates
                                               # ([hi | lo] x [W | W] executes 2 K columns for a K-column product); 0 = K
 
@@ -262,7 +263,10 @@ class HipBackend:
             cs = torch.empty(((g.M + CS_ROWS - 1) // CS_ROWS, 2, g.N), dtype=torch.float32, device=A.device)
             a.colstats = cs.data_ptr()
         need = self.lib.vgen_tapgemm_ws_bytes(C.byref(a))
-        if need:
+        if g.ws is not None:
+            assert g.ws.is_contiguous() and g.ws.numel() * g.ws.element_size() >= need
+            a.ws, a.ws_bytes = g.ws.data_ptr(), g.ws.numel() * g.ws.element_size()
+        elif need:
             ws = torch.empty(need // 4, dtype=torch.float32, device=A.device)
             a.ws, a.ws_bytes = ws.data_ptr(), need
         meta = (g.mode, g.M, g.N, K, g.epilogue, str(g.out_dtype) + ("+dw" if dw is not None else ""))
