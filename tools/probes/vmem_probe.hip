@@ -25,6 +25,9 @@ __device__ __forceinline__ int64_t lane_off(int lane, int i, int N, int64_t stri
     return (int64_t)(idx / upr) * stride + (idx % upr) * 16;
   }
   const int half = i / (N / 2), pi = i % (N / 2);       // rows 0-15 | 16-31
+  // pattern 3: the SAME 16 rows x 64 B piece as pattern 0, lanes renumbered so that a quad is one row's 64 bytes
+  // (lane l -> row l >> 2, chunk l & 3): what a ds_bpermute of the C fragment would store
+  if (PAT == 3) return (int64_t)(half * 16 + (lane >> 2)) * stride + pi * 64 + (lane & 3) * 16;
   if (PAT == 0) return (int64_t)(half * 16 + lr) * stride + pi * 64 + lq * 16;
   return (int64_t)(half * 16 + (lr & 7) + 8 * (pi & 1)) * stride + (pi >> 1) * 128 + (lq + 4 * (lr >> 3)) * 16;
 }
@@ -80,8 +83,10 @@ void run(const char* name, unsigned char* src, unsigned char* dst, int64_t sstri
          us * 1e3 / (slices * (NL + NS)));
 }
 
-int main() {
-  const int slices = 112;                         // per block, as the GEGLU launch
+int main(int argc, char** argv) {
+  const int slices = argc > 1 ? atoi(argv[1]) : 112;   // per block: 112 = the GEGLU launch, 14 = an o-proj launch (73 MB out)
+  const bool quick = argc > 2;                         // only the r05-F block
+  printf("slices per block: %d\n", slices);
   const int64_t src_bytes = 256LL * slices * 32 * 2560, dst_bytes = 256LL * slices * 32 * 2560;
   unsigned char *src, *dst;
   unsigned* sink;
@@ -96,7 +101,15 @@ int main() {
   run<2, NL, NS>(NAME, src, dst, SS, DS, slices, SH, sink);
 #define ALLX(NAME, NL, NS, SS, DS, SH, STG, WR)                      \
   run<0, NL, NS>(NAME, src, dst, SS, DS, slices, SH, sink, STG, WR); \
+  run<3, NL, NS>(NAME, src, dst, SS, DS, slices, SH, sink, STG, WR); \
   run<2, NL, NS>(NAME, src, dst, SS, DS, slices, SH, sink, STG, WR);
+  // r05 call F: is quad-contiguity all it takes?  (pattern 3 = pattern 0's pieces with the lanes renumbered)
+  ALLX("A loads, 16 share (L2)", 20, 0, 640, 640, 16, 0, 0)
+  ALLX("fp32 tile loads, private 4-slice (L2)", 20, 0, 1280, 1280, 1, 0, 4)
+  ALLX("fp32 stores [32x160], 18 MB footprint (MALL)", 0, 20, 1280, 1280, 1, 0, 0)
+  ALLX("16-bit stores [32x160] stride 1920", 0, 10, 640, 1920, 1, 0, 0)
+  ALLX("fp32 loads + fp32 stores (residual + out)", 20, 20, 1280, 1280, 1, 0, 0)
+  if (quick) return 0;
   ALLX("A loads, 16 share, staggered by 7 slices", 20, 0, 640, 640, 16, 7, 0)
   ALLX("A loads, 2 share, staggered", 20, 0, 640, 640, 2, 7, 0)
   ALLX("A loads, private 4-slice footprint (L2)", 20, 0, 640, 640, 1, 0, 4)

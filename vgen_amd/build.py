@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "libvgen_hip.so")
 SOURCES = ["cabi.cpp", "tapgemm.hip", "panelgemm.hip", "norms.hip", "attention.hip", "misc.hip", "stems.hip"]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "tapgemm_plans.inc"),
            os.path.join(HERE, "..", "include", "vgen_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
          "-x", "hip"]
 
 

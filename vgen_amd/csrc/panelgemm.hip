@@ -25,6 +25,7 @@
 #include "common.h"
 
 #include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -49,6 +50,27 @@ __device__ __forceinline__ void glds16(const void* src, unsigned char* lds_wave_
 #else
 #define PANEL_STAMP(i)
 #endif
+
+// The A-chunk DMAs of the slice loop are issued through inline asm: hipcc books a `global_load_lds` as an access that may
+// touch LDS through the flat path, and from then on degrades every counted lgkmcnt of the loop to lgkmcnt(0) — the W
+// fragment ring (8 reads ahead) would drain twice per chunk.  The asm is invisible to that bookkeeping (its extra VMEM
+// operations only make the compiler's own vmcnt waits stricter); the waits that order these DMAs against the fragment
+// reads of their slot are the explicit ones in the loop.  m0 <- LDS byte address; one wait state before its use.
+__device__ __forceinline__ void glds16_asm(const void* src, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(lds_addr) : "memory", "m0");
+}
+
+// compile-time loop: f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>).  (`#pragma unroll` is not enough
+// for the main loop: with inline asm in its body hipcc keeps a run-time loop and indexes the register arrays through
+// s_set_gpr_idx — 30 instructions between two MFMAs.)
+template <int... I, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, I...>, F&& f) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(std::make_integer_sequence<int, N>{}, static_cast<F&&>(f));
+}
 
 constexpr int PANEL_WAVES = 8;
 constexpr int SLICE_ROWS = 32;
@@ -94,20 +116,41 @@ __global__ __launch_bounds__(PANEL_WAVES * 64) void panel_kernel(const vgen_tapg
   const uint16_t* __restrict__ W = (const uint16_t*)p.W;
   const int64_t ldw = p.ldw ? p.ldw : (int64_t)KS * 32 * (DW ? 2 : 1);
 
-  // ---- A fragments of one 32-row slice: straight from global memory into MFMA layout ----------------------------
-  u32x4 xa[MF][KS];
-  auto load_a = [&](int s) __attribute__((always_inline)) {
+  // ---- the A operand: per-WAVE staging ring in LDS, filled by LDS-DMA ---------------------------------------------------
+  // r05 call C / D (profiles/r05c_panel_stamps.json, r05d_vmem_probe.txt): loading the fragments straight from row-major
+  // memory into MFMA layout (lane (lr, lq) = row lr, 16 bytes at chunk lq: every quad of lanes touches 4 different rows)
+  // runs at 17.5 B/clk/CU wherever the data sits — the texture addresser splits each quad that is not 64 contiguous
+  // bytes — and made the first version of this kernel VMEM-issue-bound (20 such loads per slice took 1.7 - 5.6 k cycles
+  // to issue against a 3.2 - 4 k cycle MFMA loop).  LDS-DMA with lane-linear sources moves the same bytes at 25 - 45
+  // B/clk/CU.  Each wave owns a ring of ARING chunks of [32 rows x 32 k] (2 KiB = 2 DMA instructions of 16 rows x 64 B,
+  // quad = one 64-byte piece); nobody else touches it, so the only synchronisation is the wave's own vmcnt / lgkmcnt:
+  // chunk g + 3 is issued into the slot chunk g was read out of (its two fragments sit in registers by then), chunk
+  // g + 1 is read into the other half of a register double buffer while chunk g multiplies.
+  constexpr int ACH = 2048, ARING = 3;
+  unsigned char* const abuf = smem + W_BYTES + BN * sizeof(float) + wave * (ARING * ACH);
+  const int a_r16 = lane >> 2, a_c = lane & 3;
+  const int a_src_chunk = (a_c ^ ((4 - ((a_r16 >> 2) & 3)) & 3)) << 3;             // swz_key<4> of tapgemm.hip, in elements
+  const unsigned char* const ard = abuf + lr * 64 + ((lq ^ ((4 - ((lr >> 2) & 3)) & 3)) << 4);
+  auto a_ptrs = [&](int sl, const uint16_t* (&ap)[2]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int mi = 0; mi < MF; ++mi) {
-      int row = s * SLICE_ROWS + mi * 16 + lr;
+    for (int j = 0; j < 2; ++j) {
+      int row = sl * SLICE_ROWS + j * 16 + a_r16;
       row = row < M ? row : M - 1;                           // tail rows re-read the last row; never stored
-      const uint16_t* ap = A + (int64_t)row * p.lda + lq * 8;
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk) xa[mi][kk] = *(const u32x4*)(ap + kk * 32);
+      ap[j] = A + (int64_t)row * p.lda + a_src_chunk;
     }
   };
+  const unsigned abuf_lds = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)abuf;
+  auto a_dma = [&](const uint16_t* const (&ap)[2], int kk, int slot_off) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) glds16_asm(ap[j] + kk * 32, abuf_lds + slot_off + j * 1024);
+  };
   int s = s_begin + wave;
-  if (s < s_end) load_a(s);                                  // in flight while the panel is staged
+  const uint16_t* ap_cur[2];
+  if (s < s_end) {
+    a_ptrs(s, ap_cur);
+#pragma unroll
+    for (int kk = 0; kk < ARING; ++kk) a_dma(ap_cur, kk, kk * ACH);      // in flight while the panel is staged
+  }
 
   // ---- stage the W panel: KT tiles of [LROWS][64] 16-bit, chunk c of row r at ((c ^ (r & 7)) << 4) ---------------
   {
@@ -135,11 +178,16 @@ __global__ __launch_bounds__(PANEL_WAVES * 64) void panel_kernel(const vgen_tapg
   long long seg[6] = {0, 0, 0, 0, 0, 0};
   long long tprev = stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
 #endif
+  int ring0 = 0;                                             // ring slot of this slice's chunk 0 (chunk kk: (ring0 + kk) % 3)
   for (; s < s_end; s += PANEL_WAVES) {
     const int mrow0 = s * SLICE_ROWS;
+    const bool has_next = s + PANEL_WAVES < s_end;
+    int soff[ARING];                                         // LDS offset of the slot of chunk kk: soff[kk % 3]
+#pragma unroll
+    for (int j = 0; j < ARING; ++j) soff[j] = ((ring0 + j) % ARING) * ACH;
     f32x4 acc[NF][MF];
-    // accumulators start from the fp32 residual tile (same as tapgemm.hip: the loads land while the A fragments do); tail
-    // rows / columns re-read a valid address and are never stored, so the loads need no per-lane predicate
+    // accumulators start from the fp32 residual tile (same as tapgemm.hip: the loads land while the A chunks do); tail
+    // rows re-read a valid address and are never stored, so the loads need no per-lane predicate
     if (res_folded) {
 #pragma unroll
       for (int mi = 0; mi < MF; ++mi) {
@@ -155,38 +203,71 @@ __global__ __launch_bounds__(PANEL_WAVES * 64) void panel_kernel(const vgen_tapg
 #pragma unroll
         for (int ni = 0; ni < NF; ++ni) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-
     PANEL_STAMP(0)
-#ifdef VGEN_TUNING
-    if (stamps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
+    // everything this wave has in flight lands here: chunks 0 - 2 of this slice (issued three chunks ago), the residual
+    // tile, the previous slice's stores.  (One vmcnt serves loads and stores, so a counted wait past the stores would
+    // have to assume their completion order.)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     PANEL_STAMP(1)
-    // ---- KS * NFL W fragments against the resident panel, two MFMAs each; the fragment reads run RING fragments ahead
-    // of their MFMAs (left to itself hipcc serialises read -> lgkmcnt(0) -> 2 MFMAs through ONE fragment register) -------
+
+    // ---- KS chunks x NFL W fragments against the resident panel, two MFMAs each.  The W fragment reads run RING
+    // fragments ahead of their MFMAs (left to itself hipcc serialises read -> lgkmcnt(0) -> 2 MFMAs through ONE register)
     constexpr int NT = KS * NFL;
-    constexpr int RING = NF >= 10 ? 4 : 6;                    // 16 / 24 VGPRs of fragments in flight (the 160-column panel has no more to spare)
+    constexpr int RING = 8;
     u32x4 wring[RING];
+    u32x4 xa[2][MF];                                          // A fragments of chunk kk in xa[kk & 1]
     auto wread = [&](int t) __attribute__((always_inline)) -> u32x4 {
       const int kk = t / NFL, nfl = t % NFL;
       return *(const u32x4*)(wrd + (kk >> 1) * TILE_BYTES + ((((kk & 1) * 4 + lq) ^ sw) << 4) + nfl * 16 * 128);
     };
+    auto aread = [&](int kk) __attribute__((always_inline)) {
+#pragma unroll
+      for (int mi = 0; mi < MF; ++mi) xa[kk & 1][mi] = *(const u32x4*)(ard + soff[kk % ARING] + mi * 1024);
+    };
+    aread(0);
 #pragma unroll
     for (int t = 0; t < RING; ++t) wring[t] = wread(t);
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      const int kk = t / NFL, nfl = t % NFL;
-      const int ni = DW ? nfl % NF : nfl;
+    const uint16_t* ap_nxt[2];
+    static_for<NT>([&](auto tc) __attribute__((always_inline)) {
+      constexpr int t = decltype(tc)::value;
+      constexpr int kk = t / NFL, nfl = t % NFL;
+      constexpr int ni = DW ? nfl % NF : nfl;
       const u32x4 wv = wring[t % RING];
 #pragma unroll
-      for (int mi = 0; mi < MF; ++mi) acc[ni][mi] = T::mfma32(wv, xa[mi][kk], acc[ni][mi]);
-      if (t + RING < NT) wring[t % RING] = wread(t + RING);
+      for (int mi = 0; mi < MF; ++mi) acc[ni][mi] = T::mfma32(wv, xa[kk & 1][mi], acc[ni][mi]);
+      if constexpr (t + RING < NT) wring[t % RING] = wread(t + RING);
+      // chunk kk + 3 goes into the slot chunk kk came out of (its fragments were waited for by the MFMAs just issued).
+      // In chunk 0 it is issued LAST: hipcc waits for the residual loads accumulator by accumulator (vmcnt(19) ... (0)
+      // through the chunk's first touches) without knowing that the vmcnt(0) above already covered them — a DMA it cannot
+      // see in the queue would turn its last vmcnt(0) into a wait for that DMA.
+      if constexpr (nfl == (kk == 0 ? NFL - 1 : 0)) {
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (kk + ARING < KS) {
+          a_dma(ap_cur, kk + ARING, soff[kk % ARING]);
+        } else {
+          if (has_next) {
+            if constexpr (kk + ARING == KS) a_ptrs(s + PANEL_WAVES, ap_nxt);
+            a_dma(ap_nxt, kk + ARING - KS, soff[kk % ARING]);
+          }
+        }
+      }
+      if constexpr (nfl == 2 && kk + 1 < KS) {
+        // chunk kk + 1 must have landed; newer than it in the queue: chunks kk + 2, kk + 3 (2 DMA instructions each) —
+        // fewer at the tail of the wave's last slice, where nothing follows
+        if (has_next || kk + 1 + 2 < KS) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else if (kk + 1 + 1 < KS) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        aread(kk + 1);
+      }
       __builtin_amdgcn_sched_barrier(0);
-    }
+    });
     __builtin_amdgcn_sched_barrier(0);
     PANEL_STAMP(2)
-    // the A registers are dead: the next slice's loads fly while this slice's epilogue converts and stores
-    if (s + PANEL_WAVES < s_end) load_a(s + PANEL_WAVES);
-    __builtin_amdgcn_sched_barrier(0);
+    if (has_next) {
+      ap_cur[0] = ap_nxt[0];
+      ap_cur[1] = ap_nxt[1];
+    }
+    ring0 = (ring0 + KS) % ARING;
     PANEL_STAMP(3)
 
     // ---- epilogue (N % BN == 0 is an eligibility condition: no column guards) -------------------------------------
@@ -252,7 +333,7 @@ __global__ __launch_bounds__(PANEL_WAVES * 64) void panel_kernel(const vgen_tapg
 template <typename T, int KS, int BN, bool DW, int EPI>
 int launch_panel(const vgen_tapgemm_args& a, hipStream_t stream) {
   constexpr int LROWS = DW ? 2 * BN : BN;
-  constexpr size_t lds = (size_t)(KS / 2) * LROWS * 128 + BN * sizeof(float);
+  constexpr size_t lds = (size_t)(KS / 2) * LROWS * 128 + BN * sizeof(float) + PANEL_WAVES * 3 * 2048;   // panel | bias | A rings
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)panel_kernel<T, KS, BN, DW, EPI>,
