@@ -719,7 +719,8 @@ def main():
         tot_ms, tot_fl = sum(ms), sum(fl)
         ach = tot_fl / (tot_ms * 1e-3) / 1e12
         ndw = sum(1 for r in recs if str(r[4][5]).endswith("+dw"))
-        res["roofline"] = {"kernel": "tapgemm_kernel", "bound": "mfma", "achieved": round(ach, 2),
+        res["roofline"] = {"kernel": "tap-GEMM class: tapgemm_kernel (streaming shapes) + panel_kernel (W-panel-resident, K = 320)",
+                           "bound": "mfma", "achieved": round(ach, 2),
                            "peak": PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_TFLOPS, 4),
                            "traffic": None, "launches_per_step": len(recs), "dual_w_launches": ndw,
                            "avg_launch_us": round(1e3 * tot_ms / max(len(recs), 1), 2),
@@ -733,10 +734,18 @@ def main():
                            # issued MFMA work / the products' own 2 M N K: the W_lo passes of the dual-W launches AND the
                            # doubled K columns of two-term activation segments (r03 booked the latter as algorithmic)
                            "executed_over_algorithmic": round(sum(r[5][1] for r in recs) / max(tot_fl, 1.0), 3),
-                           "measured_in_this_run": True}
+                           "measured_in_this_run": True,
+                           # r05: what actually caps these kernels below the MFMA roofline — the CU's vector-memory path
+                           # (tools/probes/vmem_probe.hip on this chip; not measured in this run)
+                           "cu_vmem_ceiling_committed": {
+                               "source": "profiles/r05d_vmem_probe.txt, r05f_vmem_probe_quad.txt",
+                               "l2_to_cu_B_per_clk_per_cu": {"lds_dma_1KiB_linear": 27, "quad_contiguous_16rows_x_64B": 47,
+                                                             "mfma_operand_layout_straight_from_rows": 17.5},
+                               "note": "a 256 x 160 x 64 K-step stages 52 KiB per CU: at 27 B/clk that is 1.9 k cycles = the "
+                                       "measured K-step; 85-98 FLOP per staged byte x 14.5 TB/s chip-wide = 1.2-1.4 PFLOP/s"}}
         # HBM-side bytes per launch cannot be read from inside the process: they come from committed rocprofv3 PMC
         # passes of this command (tools/collect_evidence.sh -> profiles/) and are labelled as such
-        for tname in ("r04_tapgemm_traffic.json", "r03_tapgemm_traffic.json", "r02_tapgemm_traffic.json"):
+        for tname in ("r05_tapgemm_traffic.json", "r04_tapgemm_traffic.json", "r03_tapgemm_traffic.json", "r02_tapgemm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))

@@ -105,6 +105,15 @@ def main():
             d = (ref["panel"] - ref["stream"]).norm() / ref["stream"].norm()
             res["panel_vs_stream_rel_l2"] = float(d)
             res["stream_TFLOPs_rot"] = round(fl / res["stream_rot_us"] / 1e6, 1)
+        if "--stagger-scan" in sys.argv:
+            # head start of waves 0-3 over their SIMD partners (x 64 cycles; tuning build: VGEN_PANEL_STAGGER)
+            os.environ["VGEN_TAPGEMM_PANEL"] = "1"
+            scan = {}
+            for sg in (0, 16, 32, 48, 64, 96, 128):
+                os.environ["VGEN_PANEL_STAGGER"] = str(sg)
+                scan[sg] = [round(timeit(specs[:1], outs[:1], 30), 2), round(timeit(specs, outs, 5 * rot), 2)]
+            os.environ.pop("VGEN_PANEL_STAGGER")
+            res["stagger_scan_hot_rot_us"] = scan
         if "--stamps" in sys.argv:
             # per-wave s_memtime sums per segment of the slice loop (tuning build, csrc/panelgemm.hip PANEL_STAMP)
             os.environ["VGEN_TAPGEMM_PANEL"] = "1"

@@ -6,7 +6,7 @@ Kernel classes: tapgemm (all instantiations), splitk_reduce, flash, temporal, gr
 layernorm, other.  Counters are summed over a dispatch's rows (one row per XCD/SE instance) and averaged per launch."""
 import collections, csv, json, re, sys
 
-CLASSES = [("tapgemm", r"tapgemm_kernel"), ("splitk_reduce", r"splitk_reduce"), ("flash_attention", r"flash_kernel"),
+CLASSES = [("tapgemm", r"tapgemm_kernel|panel_kernel"), ("splitk_reduce", r"splitk_reduce"), ("flash_attention", r"flash_kernel"),
            ("temporal_attention", r"temporal_kernel"), ("groupnorm", r"gn_(stats|finalize|finalize_cs|apply|fused|regs)"),
            ("layernorm", r"layernorm"), ("linear_f32", r"linear_f32")]
 

@@ -27,6 +27,8 @@ __device__ __forceinline__ int64_t lane_off(int lane, int i, int N, int64_t stri
   const int half = i / (N / 2), pi = i % (N / 2);       // rows 0-15 | 16-31
   // pattern 3: the SAME 16 rows x 64 B piece as pattern 0, lanes renumbered so that a quad is one row's 64 bytes
   // (lane l -> row l >> 2, chunk l & 3): what a ds_bpermute of the C fragment would store
+  // pattern 4: 8 rows x 128 B per instruction (lane l -> row l >> 3, chunk l & 7): the streaming shapes' BK = 64 DMA piece
+  if (PAT == 4) return (int64_t)(half * 16 + (lane >> 3) + 8 * (pi & 1)) * stride + (pi >> 1) * 128 + (lane & 7) * 16;
   if (PAT == 3) return (int64_t)(half * 16 + (lane >> 2)) * stride + pi * 64 + (lane & 3) * 16;
   if (PAT == 0) return (int64_t)(half * 16 + lr) * stride + pi * 64 + lq * 16;
   return (int64_t)(half * 16 + (lr & 7) + 8 * (pi & 1)) * stride + (pi >> 1) * 128 + (lq + 4 * (lr >> 3)) * 16;
@@ -103,6 +105,19 @@ int main(int argc, char** argv) {
   run<0, NL, NS>(NAME, src, dst, SS, DS, slices, SH, sink, STG, WR); \
   run<3, NL, NS>(NAME, src, dst, SS, DS, slices, SH, sink, STG, WR); \
   run<2, NL, NS>(NAME, src, dst, SS, DS, slices, SH, sink, STG, WR);
+  // r05 call H: the streaming shapes' DMA piece (8 rows x 128 B) against 16 rows x 64 B, by row stride and sharing
+  if (argc > 3) {
+#define H4(NAME, SS, SH, WR)                                                   \
+  run<4, 20, 0>(NAME, src, dst, SS, SS, slices, SH, sink, 0, WR);              \
+  run<3, 20, 0>(NAME, src, dst, SS, SS, slices, SH, sink, 0, WR);
+    H4("row stride  640 B, 16 share", 640, 16, 0)
+    H4("row stride  640 B, 4 share", 640, 4, 0)
+    H4("row stride 1280 B, 16 share", 1280, 16, 0)
+    H4("row stride 2560 B, 8 share", 2560, 8, 0)
+    H4("row stride 2560 B, private 4-slice (L2)", 2560, 1, 4)
+    H4("row stride  640 B, private 4-slice (L2)", 640, 1, 4)
+    return 0;
+  }
   // r05 call F: is quad-contiguity all it takes?  (pattern 3 = pattern 0's pieces with the lanes renumbered)
   ALLX("A loads, 16 share (L2)", 20, 0, 640, 640, 16, 0, 0)
   ALLX("fp32 tile loads, private 4-slice (L2)", 20, 0, 1280, 1280, 1, 0, 4)

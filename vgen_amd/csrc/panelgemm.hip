@@ -4,26 +4,34 @@
 //
 // Why another shape.  A K = 320 launch on the streaming shapes of tapgemm.hip is 5-10 K-steps per tile: the tile's fixed
 // cost (operand prologue, two barriers per K-step, an epilogue that overlaps nothing inside its block) is ~9 K-steps'
-// worth of time, i.e. most of the launch (2-3 x the floor on every level-0 linear).  Here nothing of that is left:
+// worth of time, i.e. most of the launch (NOTES §8: 2-3 x the floor on every level-0 linear).  Here:
 //   * one block per CU, persistent.  It owns ONE panel of 160 weight rows (all of K: 100 KiB) and stages it into LDS ONCE
 //     (LDS-DMA, same bank swizzle as tapgemm.hip's stages); the 8 waves only READ it afterwards, so the main loop has no
-//     s_barrier and no LDS write at all.
-//   * the activation operand never touches LDS: every wave loads the A fragments of its own 32-row slice straight from
-//     global memory into MFMA layout (lane (lr, lq) = row lr, k = 32 ks + 8 lq ... + 7 is one 16-byte load; the 4 lanes of
-//     a row read 64 contiguous bytes) — 80 VGPRs for the whole K extent — and multiplies it against the resident panel:
-//     200 MFMAs per slice, one ds_read_b128 of W per TWO MFMAs (128 B/clk of the LDS's 256).
-//   * waves are independent: wave w walks slices w, w + 8, ... of the block's row range; its A loads for the next slice are
-//     issued before its epilogue, and the partner wave on the same SIMD multiplies while it loads / converts / stores —
-//     the overlap the "dual" shape buys with a second block, without a second copy of the weights.
+//     s_barrier: every wave walks its own 32-row slices (w, w + 8, ... of the block's row range), 200 MFMAs per slice, one
+//     ds_read_b128 of W per TWO MFMAs (128 B/clk of the LDS's 256), the fragment reads running 8 ahead of their MFMAs.
+//   * the A operand reaches the wave through its PRIVATE LDS ring (3 chunks of [32 rows x 32 k], 6 KiB per wave), filled
+//     by LDS-DMA whose lanes read quad-contiguously (lane l -> row l >> 2, 16 bytes at chunk l & 3: 47 B/clk/CU from L2).
+//     The first version loaded the fragments straight into MFMA layout (lane (lr, lq) = row lr, chunk lq: every QUAD of
+//     lanes touches four different rows) — the texture addresser splits such a load into 64 requests and caps it at
+//     17.5 B/clk/CU wherever the data sits (tools/probes/vmem_probe.hip, profiles/r05d / r05f): the kernel was bound by
+//     VMEM issue, not by the matrix pipe.  Only the wave's own vmcnt / lgkmcnt order ring and reads — no barrier.
+//   * waves are independent, so one wave's epilogue (bias, GEGLU gate, conversion, stores — as long as its MFMA loop:
+//     the store path takes ~10 B/clk/CU) runs under its SIMD partner's MFMAs — provided the two are out of phase: waves
+//     4-7 start PANEL_STAGGER x 64 cycles late.
 //   * dual-W (vgen_tapgemm_args.dualw): the panel is 80 output columns, LDS rows 0-79 = W_hi, 80-159 = W_lo, both
-//     accumulate into the same 80-column accumulators; A is loaded and held once.  (GEGLU + dual-W: 64 columns.)
+//     accumulate into the same 80-column accumulators; A is staged once.  (GEGLU + dual-W: 64 columns.)
 //   * blocks of one row range (all column panels) sit on the same XCD (block b -> XCD b % 8 renumbering), so the A rows
 //     every panel re-reads come out of that XCD's L2: HBM sees A once.
 // Same operand swap and C/D layout as tapgemm.hip (D[n][m]: a lane holds 4 consecutive n of one row m), same epilogue
 // arithmetic order (bias, then residual through the accumulator's initial value; GEGLU gate polynomial; paired 16-byte
-// 16-bit stores) — results differ from the streaming shapes by fp32 summation order only.
+// 16-bit stores): single-pass results are BIT-IDENTICAL to the streaming shapes' (one accumulator chain per output in the
+// same k order), dual-W ones differ by summation order (5e-6).
+// Measured (MI355X, same process, operands not cache-resident; profiles/r05e_panel_probe_dma.json, r05g): GEGLU
+// 57344 x 2560 x 320 175 -> 118 us, q/k/v 57344 x 960 x 320 85 -> 64 us (dual-W 114 -> 86), out-projection with fp32
+// residual 55 -> 49 us (HBM-bound: 183 MB), whole t2v step -4 % in same-box A/Bs.
 #include "common.h"
 
+#include <stdlib.h>
 #include <type_traits>
 #include <utility>
 
@@ -74,11 +82,15 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 constexpr int PANEL_WAVES = 8;
 constexpr int SLICE_ROWS = 32;
+// x 64 cycles: head start of waves 0-3 over their SIMD partners 4-7.  Scanned 0 ... 128 per shape on the GPU
+// (profiles/r05g_panel_stagger.json): GEGLU 138 -> 118 us at 64, q / qkv -4 ... -5 %, the HBM-bound fp32 launches +-1 %.
+constexpr int PANEL_STAGGER = 64;
 
 enum { EPI_F32 = 0, EPI_16 = 1, EPI_GEGLU16 = 2 };   // fp32 store | 16-bit store | GEGLU gate + 16-bit store
 
 template <typename T, int KS, int BN, bool DW, int EPI>
-__global__ __launch_bounds__(PANEL_WAVES * 64) void panel_kernel(const vgen_tapgemm_args p, const int P, const int Cn) {
+__global__ __launch_bounds__(PANEL_WAVES * 64) void panel_kernel(const vgen_tapgemm_args p, const int P, const int Cn,
+                                                                  const int stagger) {
   constexpr int KT = KS / 2;                  // 64-element K-tiles of the LDS panel
   constexpr int LROWS = DW ? 2 * BN : BN;     // LDS rows: [W_hi rows | W_lo rows] with dual-W
   constexpr int NFL = LROWS / 16;             // W fragments per 32-element k-step
@@ -168,6 +180,13 @@ __global__ __launch_bounds__(PANEL_WAVES * 64) void panel_kernel(const vgen_tapg
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  // Waves w and w + 4 share a SIMD, leave the barrier together and have identical work: left alone they run their MFMA
+  // loops at the same time (sharing the matrix pipe) and their epilogues at the same time (pipe idle) — the stamps of
+  // r05 call E show an MFMA loop of ~2 x its stand-alone length.  The second wave of every SIMD starts `stagger` x 64
+  // cycles late, so that one multiplies while the other converts and stores.
+  if (wave >= PANEL_WAVES / 2) {
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(1);
+  }
 
   const unsigned char* const wrd = smem + lr * 128;          // this lane's row inside a 16-row fragment
   const int sw = lr & 7;
@@ -349,8 +368,12 @@ int launch_panel(const vgen_tapgemm_args& a, hipStream_t stream) {
   const int nslices = (int)((a.M + SLICE_ROWS - 1) / SLICE_ROWS);
   if (Cn > nslices) Cn = nslices;
   if (Cn < 1) Cn = 1;
+  int stagger = PANEL_STAGGER;
+#ifdef VGEN_TUNING
+  if (const char* e = getenv("VGEN_PANEL_STAGGER")) stagger = atoi(e);
+#endif
   hipLaunchKernelGGL((panel_kernel<T, KS, BN, DW, EPI>), dim3((unsigned)(P * Cn)), dim3(PANEL_WAVES * 64), lds, stream, a, P,
-                     Cn);
+                     Cn, stagger);
   return vgen_check_launch("tapgemm(panel)");
 }
 
