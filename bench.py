@@ -738,11 +738,12 @@ def main():
                            # r05: what actually caps these kernels below the MFMA roofline — the CU's vector-memory path
                            # (tools/probes/vmem_probe.hip on this chip; not measured in this run)
                            "cu_vmem_ceiling_committed": {
-                               "source": "profiles/r05d_vmem_probe.txt, r05f_vmem_probe_quad.txt",
-                               "l2_to_cu_B_per_clk_per_cu": {"lds_dma_1KiB_linear": 27, "quad_contiguous_16rows_x_64B": 47,
-                                                             "mfma_operand_layout_straight_from_rows": 17.5},
-                               "note": "a 256 x 160 x 64 K-step stages 52 KiB per CU: at 27 B/clk that is 1.9 k cycles = the "
-                                       "measured K-step; 85-98 FLOP per staged byte x 14.5 TB/s chip-wide = 1.2-1.4 PFLOP/s"}}
+                               "source": "profiles/r05d_vmem_probe.txt, r05f_vmem_probe_quad.txt, r05h_vmem_probe_pieces.txt",
+                               "B_per_clk_per_cu": {"mfma_operand_layout_straight_from_rows": 17.5,
+                                                    "quad_contiguous_pieces_to_registers_or_lds_dma": "41-59",
+                                                    "stores_any_pattern": "10-12"},
+                               "note": "a streaming 256 x 160 x 64 K-step stages 52 KiB per CU: >= 1.1 k cycles of this path "
+                                       "beside 1.28 k cycles of MFMAs; stamped K-step 2.0 k cycles (DESIGN 3.1)"}}
         # HBM-side bytes per launch cannot be read from inside the process: they come from committed rocprofv3 PMC
         # passes of this command (tools/collect_evidence.sh -> profiles/) and are labelled as such
         for tname in ("r05_tapgemm_traffic.json", "r04_tapgemm_traffic.json", "r03_tapgemm_traffic.json", "r02_tapgemm_traffic.json"):

@@ -64,6 +64,45 @@ __global__ __launch_bounds__(512) void vmem_kernel(const unsigned char* __restri
   if (acc.x == 0x12345678u && acc.y == 0x9abcdef0u) sink[0] = acc.z;
 }
 
+// the same 8 rows x 128 B pieces moved by LDS-DMA (global_load_lds_dwordx4) into a per-wave 4-KiB LDS ring instead of
+// registers: what the staging path of the streaming tap-GEMM shapes can take
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+__global__ __launch_bounds__(512) void dma_kernel(const unsigned char* __restrict__ src, int64_t src_stride, int slices,
+                                                  int share, int wrap, unsigned* sink) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[8 * 4096];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const unsigned nwg = gridDim.x, bid = blockIdx.x;
+  const unsigned L = (bid & 7u) * (nwg >> 3) + (bid >> 3);
+  const int rdgrp = L / share;
+  for (int s = wave; s < slices; s += 8) {
+    int sr = wrap ? s % wrap : s;
+    const unsigned char* sp = src + ((int64_t)rdgrp * slices + sr) * 32 * src_stride;
+#pragma unroll
+    for (int i = 0; i < 20; ++i)
+      __builtin_amdgcn_global_load_lds((gptr_t)(sp + lane_off<4>(lane, i, 20, src_stride, 640)),
+                                       (lptr_t)(lds + wave * 4096 + (i & 3) * 1024), 16, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  if (lds[threadIdx.x] == 0x5a && lds[threadIdx.x + 512] == 0xa5) sink[1] = 1;
+}
+
+void run_dma(const char* name, unsigned char* src, int64_t sstride, int slices, int share, int wrap, unsigned* sink) {
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0);
+  hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(dma_kernel, dim3(256), dim3(512), 0, 0, src, sstride, slices, share, wrap, sink);
+  hipEventRecord(e0);
+  const int it = 10;
+  for (int i = 0; i < it; ++i) hipLaunchKernelGGL(dma_kernel, dim3(256), dim3(512), 0, 0, src, sstride, slices, share, wrap, sink);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms;
+  hipEventElapsedTime(&ms, e0, e1);
+  const double us = ms * 1e3 / it, lb = 256.0 * slices * 20 * 1024;
+  printf("%-44s LDS-DMA 8x128B pieces: %8.1f us  %7.1f GB/s (%5.1f B/clk/CU @2.1GHz)\n", name, us, lb / us / 1e3, lb / us / 1e3 / 256 / 2.1);
+}
+
 template <int PAT, int NL, int NS>
 void run(const char* name, unsigned char* src, unsigned char* dst, int64_t sstride, int64_t dstride, int slices, int share,
          unsigned* sink, int stagger = 0, int wrap = 0) {
@@ -110,6 +149,9 @@ int main(int argc, char** argv) {
 #define H4(NAME, SS, SH, WR)                                                   \
   run<4, 20, 0>(NAME, src, dst, SS, SS, slices, SH, sink, 0, WR);              \
   run<3, 20, 0>(NAME, src, dst, SS, SS, slices, SH, sink, 0, WR);
+    run_dma("row stride  640 B, 16 share", src, 640, slices, 16, 0, sink);
+    run_dma("row stride 2560 B, 8 share", src, 2560, slices, 8, 0, sink);
+    run_dma("row stride  640 B, private 4-slice (L2)", src, 640, slices, 1, 4, sink);
     H4("row stride  640 B, 16 share", 640, 16, 0)
     H4("row stride  640 B, 4 share", 640, 4, 0)
     H4("row stride 1280 B, 16 share", 1280, 16, 0)

@@ -13,7 +13,7 @@
 //     by LDS-DMA whose lanes read quad-contiguously (lane l -> row l >> 2, 16 bytes at chunk l & 3: 47 B/clk/CU from L2).
 //     The first version loaded the fragments straight into MFMA layout (lane (lr, lq) = row lr, chunk lq: every QUAD of
 //     lanes touches four different rows) — the texture addresser splits such a load into 64 requests and caps it at
-//     17.5 B/clk/CU wherever the data sits (tools/probes/vmem_probe.hip, profiles/r05d / r05f): the kernel was bound by
+//     17.5 B/clk/CU wherever the data sits (tools/probes/vmem_probe.hip, profiles/r05d / r05f / r05h): the kernel was bound by
 //     VMEM issue, not by the matrix pipe.  Only the wave's own vmcnt / lgkmcnt order ring and reads — no barrier.
 //   * waves are independent, so one wave's epilogue (bias, GEGLU gate, conversion, stores — as long as its MFMA loop:
 //     the store path takes ~10 B/clk/CU) runs under its SIMD partner's MFMAs — provided the two are out of phase: waves
