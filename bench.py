@@ -120,6 +120,14 @@ CONFIGS = {
                      desc="videolcm 16x448x256: whole videos as the engine makes them (inference_videolcm_entrance.py:"
                           "171-258) — LCMScheduler.sample_loop, 4 steps of one UNetSD_VideoLCM fwd + LCM update (no CFG), "
                           "a NEW prompt per video, then the 16-frame AutoencoderKL decode to uint8 (decoder_bs 2)"),
+    # r05: the first stage of BASELINE config 5 with the reference's OWN composition list (configs/tft2v_vcomposer_infer.yaml:74)
+    # — six pixel-resolution condition maps summed into the concat channels, an image token; needs precision="high" at this
+    # shape (tests/golden/unet_vcomposer_full.pt: 1.04e-3 in "mixed", 8.6e-4 in "high")
+    "tft2v_vcomposer": dict(cls="unet_videolcm.UNetSD_TFT2V", cfg=dict(UNET_T2V, concat_dim=8, num_tokens=4, training=False),
+                            comps=["text", "mask", "depthmap", "sketch", "motion", "image", "local_image", "single_sketch"],
+                            latent=(4, 32, 64, 112), G=2, tflop=78.04,
+                            desc="tft2v vcomposer 32x896x512 latent [1,4,32,64,112], DDIM CFG step (2 UNetSD_TFT2V fwd + "
+                                 "update), the eight-entry vcomposer composition list"),
     # BASELINE config 5: both stages back to back for ONE video (bench.py run_two_stage)
     "tft2v_sr600": dict(cls="unet_videolcm.UNetSD_TFT2V", cfg=dict(UNET_T2V, num_tokens=4), comps=["text", "image"],
                         latent=(4, 32, 64, 112), G=2, tflop=77.94,
@@ -195,10 +203,17 @@ def conditioning(name, model, P, dev, gen):
         fps = torch.full((P,), 8, dtype=torch.long, device=dev)
         kc.update(image=img.unsqueeze(1), local_image=li, fps=fps)
         ku.update(image=torch.zeros_like(img).unsqueeze(1), local_image=li, fps=fps)
-    if name in ("tft2v896", "tft2v32f"):
+    if name in ("tft2v896", "tft2v32f", "tft2v_vcomposer"):
         img = torch.randn(P, 1, 1024, generator=gen, device=dev)
         kc.update(image=img)
         ku.update(image=torch.zeros_like(img))
+    if name == "tft2v_vcomposer":
+        # the six spatial conditions at pixel resolution (the engine passes the same maps to both CFG branches,
+        # inference_tft2v_sr600_entrance.py / unet_tf2tv.py:538-777)
+        mk = lambda ch: torch.randn(P, ch, F, H * 8, W * 8, generator=gen, device=dev).half().float()
+        maps = dict(depth=mk(1), sketch=mk(1), single_sketch=mk(1), motion=mk(2), local_image=mk(3), masked=mk(4))
+        kc.update(maps)
+        ku.update(maps)
     return [kc, ku] if c["G"] == 2 else [kc]
 
 
@@ -358,9 +373,14 @@ def run_two_stage(args, dev, world, rank):
         return time.perf_counter()
 
     # ---- stage 1 -----------------------------------------------------------------------------------------------
-    m1 = build_model("tft2v896", dev, args.dtype, args.precision)
+    s1 = "tft2v_vcomposer" if args.stage1 == "vcomposer" else "tft2v896"
+    p1 = args.stage1_precision or args.precision
+    m1 = build_model(s1, dev, args.dtype, p1)
     C, F, H, W = CONFIGS["tft2v_sr600"]["latent"]
-    kw1 = conditioning("tft2v896", m1, 1, dev, g)
+    if args.stage1 == "vcomposer":
+        kw1 = conditioning("tft2v_vcomposer", m1, 1, dev, g)
+    else:
+        kw1 = conditioning("tft2v896", m1, 1, dev, g)
     d1 = DiffusionDDIM(**DDIM)
     d1.rng_parity = False
     noise = torch.randn(1, C, F, H, W, generator=g, device=dev)
@@ -403,12 +423,16 @@ def run_two_stage(args, dev, world, rank):
         "steps": n1 + 2 * n2, "warmup": 0, "ms_per_step": round(1e3 * total / (n1 + 2 * n2), 3), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": CONFIGS["tft2v_sr600"]["desc"], "name": "tft2v_sr600", "precision": args.precision,
+                   "stage1_compositions": CONFIGS[s1]["comps"], "stage1_precision": p1,
                    "parallelism": "single GPU", "weights": "seeded synthetic (device-side random init)",
                    "smoke_run": steps1 is not None,
                    "note": "one video, cold sessions (setup + graph capture inside the timed region, as a one-shot engine "
-                           "run pays them); weight synthesis of the second model excluded; stage 1 runs the text + image "
-                           "compositions — with the whole vcomposer list at this shape precision='mixed' measures 1.01e-3 "
-                           "(tests/golden/unet_vcomposer_full.pt): run stage 1 with --precision high for <= 1e-3"},
+                           "run pays them); weight synthesis of the second model excluded; " +
+                           ("stage 1 runs the reference yaml's whole vcomposer composition list (six pixel-resolution condition "
+                            "maps) — tests/golden/unet_vcomposer_full.pt: 1.04e-3 in 'mixed', 8.6e-4 in 'high'"
+                            if args.stage1 == "vcomposer" else
+                            "stage 1 runs the text + image compositions — with the whole vcomposer list (--stage1 vcomposer) at "
+                            "this shape precision='mixed' measures 1.04e-3: pass --stage1-precision high for <= 1e-3")},
         "seconds_per_video": round(total, 3), "stages": times,
         "finite": fin1 and bool(torch.isfinite(out).all()), "video_shape": list(video.shape),
     }
@@ -432,6 +456,11 @@ def main():
                          "1.33e-3); mixed:e0d01t1-style strings select levels (vgen_amd/unet.py)")
     ap.add_argument("--variants", default="fp16/high,fp16/fast,bf16/fast",
                     help="other dtype/precision modes timed + parity-checked after the headline mode (t2v, N = 1); '' = none")
+    ap.add_argument("--stage1", default="text_image", choices=["text_image", "vcomposer"],
+                    help="--config tft2v_sr600: composition list of the first stage (vcomposer = the reference yaml's eight "
+                         "entries with six pixel-resolution condition maps)")
+    ap.add_argument("--stage1-precision", default=None, help="--config tft2v_sr600: precision of the first-stage UNet "
+                                                             "(default: --precision); the vcomposer list needs 'high' for <= 1e-3")
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of hipGraph replay")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vae", action="store_true")
