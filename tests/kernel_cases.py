@@ -383,6 +383,11 @@ def panel_cases(dt, dualw=False):
     c[px + "geglu_res"] = make_tapgemm(dt, 2500, 640, 320, epilogue=L.EPI_GEGLU, out_dtype=dt, residual=True, dualw=dualw)
     c[px + "views"] = make_tapgemm(dt, 3000, 320, 320, a_pad=64, w_pad=0 if dualw else 128, residual=True, dualw=dualw)
     c[px + "wide_N"] = make_tapgemm(dt, 2100, 1600 if not dualw else 1280, 320, out_dtype=dt, dualw=dualw)
+    if not dualw:
+        # K = 640 (the 16 x 28 level): 80-column single-pass panels, 20 A chunks per slice
+        c[px + "k640_o_proj_res_f32"] = make_tapgemm(dt, 4500, 640, 640, residual=True)
+        c[px + "k640_qkv_out16"] = make_tapgemm(dt, 3001, 1920, 640, out_dtype=dt, bias=False)
+        c[px + "k640_views"] = make_tapgemm(dt, 2050, 320, 640, a_pad=128, w_pad=64, out_dtype=dt, residual=True)
     return c
 
 

@@ -116,8 +116,12 @@ def test_plans_of_the_benchmark_launches_are_legal():
                 if shape == SHAPE_PANEL:
                     # r05, csrc/panelgemm.hip: the W-panel-resident shape takes the K = 320 linears of the full-resolution
                     # level and nothing else; 160-column panels, 80 with a two-term weight (64 under GEGLU), no split-K
-                    assert mode == lib.TAP_LINEAR and C1 == 320 and C2 == 0 and M >= 2048 and not colstats, sig
-                    assert bn == ((64 if epi else 80) if dw else 160) and N % bn == 0 and sk == 1, (sig, bn, sk)
+                    assert mode == lib.TAP_LINEAR and C1 in (320, 640) and C2 == 0 and M >= 2048 and not colstats, sig
+                    if C1 == 640:                        # the 16 x 28 level: 80-column single-pass panels, no GEGLU
+                        assert bn == 80 and not dw and not epi, (sig, bn)
+                    else:
+                        assert bn == ((64 if epi else 80) if dw else 160), (sig, bn)
+                    assert N % bn == 0 and sk == 1, (sig, bn, sk)
                     assert l.vgen_tapgemm_ws_bytes(C.byref(a)) == 0, sig
                     seen.add((shape, bn, False))
                     continue

@@ -14,7 +14,8 @@ timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>
 cd /tmp && export TMPDIR=/tmp
 PREC=${PREC:-mixed}
 B="python $R/bench.py --precision $PREC --no-graph --no-cpu-baseline --no-vae --no-roofline --no-e2e --no-parity --no-scaling-model --variants="
-timeout 600 python $R/bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err
+timeout 600 python $R/bench.py --steps 20 --warmup 5 --dump-shapes > $O/bench.json 2> $O/bench.err
+cp $R/gpurun_out/tapgemm_shapes_t2v_fp16_mixed.json $R/gpurun_out/other_shapes_t2v_fp16_mixed.json $O/ 2>/dev/null
 tail -c 1500 $O/bench.json
 P="--steps 20 --warmup 5 --no-cpu-baseline --no-vae --no-roofline --no-e2e --no-parity --no-scaling-model --variants= --partition"
 timeout 200 python $R/bench.py $P > $O/bench_partition_eager.json 2> $O/bench_partition_eager.err

@@ -73,6 +73,9 @@ def main():
         ("qkv 57344x960x320 out16 dw", dict(N=960, out16=True, dw=True)),
         ("geglu 57344x2560x320", dict(N=2560, geglu=True)),
         ("geglu 57344x2560x320 dw", dict(N=2560, geglu=True, dw=True)),
+        ("L1 qkv 14336x1920x640 out16", dict(N=1920, out16=True, M=14336, K=640)),
+        ("L1 o-proj 14336x640x640 +res f32", dict(N=640, res=True, M=14336, K=640)),
+        ("L1 q 14336x640x640 out16", dict(N=640, out16=True, M=14336, K=640)),
         ("i2vgen q 450560x320x320 out16", dict(N=320, out16=True, M=450560)),
         ("i2vgen qkv 450560x960x320 out16 dw", dict(N=960, out16=True, dw=True, M=450560)),
     ]
@@ -84,8 +87,9 @@ def main():
     for name, s in shapes:
         s = dict(s)
         m = s.pop("M", M)
-        rot = ROT if m == M else 2
-        specs = [make(dt, m, K=320, **s)]
+        kdim = s.pop("K", 320)
+        rot = ROT if m <= M else 2
+        specs = [make(dt, m, K=kdim, **s)]
         specs += [clone(specs[0], i) for i in range(rot - 1)]
         n_out = specs[0].N // 2 if specs[0].epilogue == L.EPI_GEGLU else specs[0].N
         outs = [torch.empty((m, n_out), dtype=specs[0].out_dtype, device=DEV) for _ in range(rot)]
@@ -98,7 +102,7 @@ def main():
             res[pl + "_rot_us"] = round(timeit(specs, outs, 5 * rot), 2)
             specs[0].out = None
             ref[pl] = be.tapgemm(specs[0]).float()
-        fl = 2.0 * m * specs[0].N * 320
+        fl = 2.0 * m * specs[0].N * kdim
         res["panel_TFLOPs_rot"] = round(fl / res["panel_rot_us"] / 1e6, 1)
         res["finite"] = bool(torch.isfinite(ref["panel"]).all())
         if "stream" in ref:

@@ -6,7 +6,7 @@ for every (mode, M, N, K, epilogue, output) of profiles/<shapes>.json the measur
     reach; a fp32 residual read, where a launch has one, is not in the profile's key and is NOT counted: the floor is low),
 and the same sums by (resolution level, conv | linear).
 
-    python tools/tapgemm_headroom.py [profiles/r04b_tapgemm_shapes_t2v_mixed.json]   -> profiles/r04_tapgemm_headroom.json
+    python tools/tapgemm_headroom.py [profiles/r04b_tapgemm_shapes_t2v_mixed.json [out.json]]   -> profiles/r04_tapgemm_headroom.json
 """
 import json
 import os
@@ -42,7 +42,7 @@ def main():
     out = {"source": os.path.relpath(src, ROOT), "floors": {"mfma_peak": PEAK, "in_loop_occupancy": OCC, "hbm_Bps": HBM},
            "total_ms": round(sum(r[2] for r in rows), 2), "floor_ms": round(sum(v[3] for v in by.values()), 2),
            "by_level": levels, "shapes": shapes}
-    dst = os.path.join(ROOT, "profiles", "r04_tapgemm_headroom.json")
+    dst = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "profiles", "r04_tapgemm_headroom.json")
     json.dump(out, open(dst, "w"), indent=1)
     print("total %.2f ms, floor %.2f ms" % (out["total_ms"], out["floor_ms"]))
     for l in levels:

@@ -85,6 +85,7 @@ constexpr int SLICE_ROWS = 32;
 // x 64 cycles: head start of waves 0-3 over their SIMD partners 4-7.  Scanned 0 ... 128 per shape on the GPU
 // (profiles/r05g_panel_stagger.json): GEGLU 138 -> 118 us at 64, q / qkv -4 ... -5 %, the HBM-bound fp32 launches +-1 %.
 constexpr int PANEL_STAGGER = 64;
+constexpr bool PANEL_K640 = true;     // K = 640 launches (80-column single-pass panels) take this shape too
 
 enum { EPI_F32 = 0, EPI_16 = 1, EPI_GEGLU16 = 2 };   // fp32 store | 16-bit store | GEGLU gate + 16-bit store
 
@@ -379,16 +380,32 @@ int launch_panel(const vgen_tapgemm_args& a, hipStream_t stream) {
 
 }  // namespace
 
+// K = 640 panels: on by default once measured; the tuning build can switch them off (VGEN_PANEL_K640=0) for the A/B
+static bool panel640_enabled() {
+#ifdef VGEN_TUNING
+  if (const char* e = getenv("VGEN_PANEL_K640")) return atoi(e) != 0;
+#endif
+  return PANEL_K640;
+}
+
 // which launches take the panel shape (host side; tapgemm.hip's dispatch asks before it plans a streaming shape):
 // the column-panel width, 0 = not this shape
 int vgen_panel_bn(const vgen_tapgemm_args& a) {
   const bool geglu = a.epilogue == VGEN_EPI_GEGLU;
-  if (a.mode != VGEN_TAP_LINEAR || a.taps != 1 || a.C2 != 0 || a.C1 != 320) return 0;
+  if (a.mode != VGEN_TAP_LINEAR || a.taps != 1 || a.C2 != 0 || (a.C1 != 320 && a.C1 != 640)) return 0;
   if (a.rowbias || a.colstats || a.split_out) return 0;
   if (a.M < 2048) return 0;                                  // a handful of slices per CU: the streaming shapes' split-K wins
   if (a.out_dtype == VGEN_F32 ? (a.ldo % 4 != 0 || geglu) : (a.ldo % 8 != 0)) return 0;
   if (a.residual && a.ldr % 4 != 0) return 0;
-  const int bn = a.dualw ? (geglu ? 64 : 80) : 160;
+  int bn;
+  if (a.C1 == 640) {
+    // K = 640 (the 16 x 28 level): an 80-row single-pass panel is the 100 KiB; no dual-W, no GEGLU (40 / 64-column panels
+    // would re-read A 2-4 x as often as the streaming tiles do)
+    if (a.dualw || geglu || !panel640_enabled()) return 0;
+    bn = 80;
+  } else {
+    bn = a.dualw ? (geglu ? 64 : 80) : 160;
+  }
   return a.N % bn == 0 ? bn : 0;
 }
 
@@ -396,12 +413,17 @@ template <typename T>
 static int panel_dispatch(const vgen_tapgemm_args& a, hipStream_t s) {
   const int bn = vgen_panel_bn(a);
   const int epi = a.epilogue == VGEN_EPI_GEGLU ? EPI_GEGLU16 : (a.out_dtype == VGEN_F32 ? EPI_F32 : EPI_16);
-  if (bn == 160 && epi == EPI_F32) return launch_panel<T, 10, 160, false, EPI_F32>(a, s);
-  if (bn == 160 && epi == EPI_16) return launch_panel<T, 10, 160, false, EPI_16>(a, s);
-  if (bn == 160 && epi == EPI_GEGLU16) return launch_panel<T, 10, 160, false, EPI_GEGLU16>(a, s);
-  if (bn == 80 && epi == EPI_F32) return launch_panel<T, 10, 80, true, EPI_F32>(a, s);
-  if (bn == 80 && epi == EPI_16) return launch_panel<T, 10, 80, true, EPI_16>(a, s);
-  if (bn == 64 && epi == EPI_GEGLU16) return launch_panel<T, 10, 64, true, EPI_GEGLU16>(a, s);
+  if (a.C1 == 640) {
+    if (bn == 80 && epi == EPI_F32) return launch_panel<T, 20, 80, false, EPI_F32>(a, s);
+    if (bn == 80 && epi == EPI_16) return launch_panel<T, 20, 80, false, EPI_16>(a, s);
+  } else {
+    if (bn == 160 && epi == EPI_F32) return launch_panel<T, 10, 160, false, EPI_F32>(a, s);
+    if (bn == 160 && epi == EPI_16) return launch_panel<T, 10, 160, false, EPI_16>(a, s);
+    if (bn == 160 && epi == EPI_GEGLU16) return launch_panel<T, 10, 160, false, EPI_GEGLU16>(a, s);
+    if (bn == 80 && epi == EPI_F32) return launch_panel<T, 10, 80, true, EPI_F32>(a, s);
+    if (bn == 80 && epi == EPI_16) return launch_panel<T, 10, 80, true, EPI_16>(a, s);
+    if (bn == 64 && epi == EPI_GEGLU16) return launch_panel<T, 10, 64, true, EPI_GEGLU16>(a, s);
+  }
   vgen_set_error("tapgemm(panel): launch not eligible");
   return VGEN_E_BADARG;
 }
