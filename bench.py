@@ -822,7 +822,15 @@ def main():
         torch.cuda.synchronize()
         fps = 2 * nrep / (time.perf_counter() - t1)
         res["vae"] = {"decode_frames_per_sec": round(fps, 2), "frame": args.vae_size, "decoder_bs": 2,
-                      "precision": vae.precision}
+                      "precision": vae.precision,
+                      # what the decode is held to.  The north-star states 1e-3 for the UNet only; the VAE's
+                      # bound is the reference's OWN arithmetic: its fp16-autocast decode lands 1.90e-3 from its fp32
+                      # decode (tests/golden/autocast_yardstick.json); here 1.37e-3 in "fast", 1.03e-3 in "high" (full-size
+                      # 256 x 448 golden, tests/test_gpu_model.py).  A weight-only rule cannot reach 1.1e-3 cheaply: with
+                      # EVERY weight two-term the decode is still at 1.03e-3 (activation roundings), so 82 % of the weight
+                      # error energy would have to go — i.e. nearly all of "high"'s cost.
+                      "tolerance": {"bound": "reference fp16-autocast yardstick 1.90e-3", "rel_l2_committed": {
+                          "fast": 1.37e-3, "high": 1.03e-3}, "source": "tests/golden/vae_sd_full*.pt via tests/test_gpu_model.py"}}
         if args.vae_size == "256x448":
             res["vae"]["tflops_per_s"] = round(fps * VAE_DEC_TFLOP, 2)
             # the 720p frames of BASELINE configs 3 / 5 (SR600 / I2VGen decode and the SR600 stage's encode), 2 frames a call
