@@ -139,6 +139,42 @@ def test_plans_of_the_benchmark_launches_are_legal():
     assert {b for _, b, _ in seen} >= {128, 160} and {k for _, _, k in seen} == {False, True}, seen
 
 
+def test_panel_shape_is_taken_exactly_where_it_is_legal():
+    """r05, csrc/panelgemm.hip::vgen_panel_bn — the W-panel-resident shape has no row bias, no column statistics, no
+    two-term output rows, no split-K and no N tails: every launch that needs one of those, or is too small to fill a CU's
+    eight waves, must stay on the streaming shapes; every other K = 320 / 640 linear must take it."""
+    l = lib.load()
+
+    def plan(M=57344, N=320, C1=320, dw=0, epi=lib.EPI_NONE, f32=True, taps=1, mode=lib.TAP_LINEAR, **extra):
+        a = lib.TapGemmArgs()
+        a.M, a.N, a.dtype, a.mode = M, N, lib.VGEN_F16, mode
+        a.A, a.lda, a.C1, a.taps = FAKE, C1, C1, taps
+        a.W, a.dualw = FAKE, dw
+        n_out = N // 2 if epi else N
+        a.out, a.ldo, a.out_dtype, a.epilogue = FAKE, n_out, (lib.VGEN_F32 if f32 else lib.VGEN_F16), epi
+        for k, v in extra.items():
+            setattr(a, k, v)
+        out3 = (C.c_int32 * 3)()
+        assert l.vgen_tapgemm_query_plan(C.byref(a), out3) == 0
+        return tuple(out3), l.vgen_tapgemm_ws_bytes(C.byref(a))
+
+    # taken: the level-0 launches of the step, single-pass and dual-W, every epilogue; the K = 640 single-pass ones
+    assert plan()[0] == (SHAPE_PANEL, 160, 1)
+    assert plan(dw=1)[0] == (SHAPE_PANEL, 80, 1)
+    assert plan(N=960, f32=False)[0] == (SHAPE_PANEL, 160, 1)
+    assert plan(N=2560, f32=False, epi=lib.EPI_GEGLU)[0] == (SHAPE_PANEL, 160, 1)
+    assert plan(N=2560, f32=False, epi=lib.EPI_GEGLU, dw=1)[0] == (SHAPE_PANEL, 64, 1)
+    assert plan(residual=FAKE, ldr=320) == ((SHAPE_PANEL, 160, 1), 0)
+    assert plan(M=14336, N=1920, C1=640, f32=False)[0] == (SHAPE_PANEL, 80, 1)
+    # not taken
+    for kw in (dict(rowbias=FAKE, rowbias_ld=320, rows_per_rb=1792), dict(colstats=FAKE), dict(M=2047), dict(N=336),
+               dict(C1=384), dict(C1=640, dw=1, M=14336, N=640), dict(C1=640, M=14336, N=5120, f32=False, epi=lib.EPI_GEGLU),
+               dict(f32=False, split_out=1, ldo=640), dict(N=2560, epi=lib.EPI_GEGLU, f32=True), dict(ldo=322),
+               dict(f32=False, ldo=324), dict(residual=FAKE, ldr=322)):
+        assert plan(**kw)[0][0] != SHAPE_PANEL, kw
+    assert plan(C1=64, C2=0, mode=lib.TAP_TEMPORAL3, taps=3, F=16, S=3584)[0][0] != SHAPE_PANEL
+
+
 # ---- the other hot entry points: same contract (argument checks come before any launch) ------------------------------------
 def good_attn():
     a = lib.AttnArgs()
