@@ -150,6 +150,22 @@ def make_tapgemm(dt, M, N, C1, mode=L.TAP_LINEAR, C2=0, bias=True, rowbias=0, re
     return TapGemm(**spec)
 
 
+
+def splitk_specs(dt):
+    """Launches the planner splits along K (tests/test_abi_contract.py checks on the CPU that it does): the named parity
+    cases above plus the 4 x 7 level of the benchmark step at its own shapes — the Conv3d(3,1,1) of the ResBlocks
+    (util.py:1665-1680; 28 launches per step), a 3 x 3 conv over the 2560-channel concat (util.py:848) and the FeedForward
+    down-projection with a 16-bit output (util.py:737)."""
+    c = tapgemm_cases(dt)
+    s = {k: c[k] for k in ("conv_splitk_L3", "lin_splitk_geglu", "lin_splitk_out16", "temporal_splitk")}
+    s["L3_temporal_896x1280x3840"] = make_tapgemm(dt, 2 * 16 * 28, 1280, 1280, mode=L.TAP_TEMPORAL3, F=16, S=28,
+                                                  residual=True, seed=3)
+    s["L3_conv_896x1280x11520"] = make_tapgemm(dt, 32 * 4 * 7, 1280, 1280, mode=L.TAP_CONV3X3, nimg=32, Hi=4, Wi=7, Ho=4,
+                                               Wo=7, stride=1, pad_t=1, pad_l=1, ups=0, rowbias=16 * 28, seed=4)
+    s["L3_ff2_896x1280x5120_out16"] = make_tapgemm(dt, 896, 1280, 5120, out_dtype=dt, residual=True, seed=5)
+    return s
+
+
 def case_tapgemm(be, dev, spec, want_map=False):
     ref = EMU.tapgemm(spec)
     out = be.tapgemm(_clone_spec(spec, dev))

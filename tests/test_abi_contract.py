@@ -280,3 +280,24 @@ def test_sampler_update_entry_points_reject_before_launching():
     assert frames(x=None) == VGEN_E_BADARG and b"frames_u8" in l.vgen_last_error()
     assert frames(ldx=2) == VGEN_E_BADARG                                          # row stride shorter than the channel count
     assert frames(rows=0) == 0
+
+
+def test_splitk_parity_cases_really_split():
+    """r05: split-K partials are reduced inside the launch (csrc/tapgemm.hip: the last block of a tile to arrive).  The GPU
+    cases that are meant to exercise that path (tests/kernel_cases.py::splitk_specs — the planner, not the test, decides)
+    must be planned with split-K > 1, on a streaming shape, with the [split][M][N] fp32 workspace the header promises; and
+    the plan must not depend on whether the operands live on the host or the device (the planner never looks at them)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import kernel_cases as kc
+    from vgen_amd import ops
+    be = ops.HipBackend()
+    for dt in (torch.float16, torch.bfloat16):
+        for name, spec in kc.splitk_specs(dt).items():
+            shape, bn, sk = be.tapgemm_plan(spec)
+            assert shape in (SHAPE_PP, SHAPE_DUAL, SHAPE_PP128) and sk > 1, (name, shape, bn, sk)
+            a = be._tapgemm_args(spec)
+            assert a[0].ws_bytes == sk * spec.M * spec.N * 4 and a[-1] is not None, (name, sk, a[0].ws_bytes)
+            tiles = -(-spec.M // (128 if shape == SHAPE_PP128 else 256)) * -(-spec.N // bn)
+            assert tiles <= 2048, (name, tiles)          # SK_MAX_TILES: more tiles than tickets would run unsplit

@@ -50,6 +50,37 @@ def test_tapgemm(hip_backend, dtname, name):
         assert cs["finite"] and cs["rel_l2"] <= 2e-5, cs
 
 
+@pytest.mark.parametrize("dtname", ["bf16", "fp16"])
+def test_splitk_reduces_inside_the_launch(hip_backend, dtname):
+    """r05: the partial tiles of a split-K launch are summed by the last block of each tile to arrive (one agent-scope
+    ticket per tile, csrc/tapgemm.hip) — no reducer launch.  Every split launch of the list is issued 12 times, interleaved
+    with the others on one stream (the tickets must be back at zero after every launch, whichever block drew the last one)
+    into a workspace pre-filled with NaN (a partial read before its writer released it, or a stale line, would surface):
+    each output must match the emulator and be BIT-identical to the first run of the same launch."""
+    dt = kc.DTS[dtname]
+    specs = kc.splitk_specs(dt)
+    dev_specs, first = {}, {}
+    for name, spec in specs.items():
+        g = kc._clone_spec(spec, DEV)
+        shape, bn, sk = hip_backend.tapgemm_plan(g)
+        assert sk > 1, (name, shape, bn, sk)
+        g.ws = torch.full((sk * g.M * g.N,), float("nan"), dtype=torch.float32, device=DEV)
+        dev_specs[name] = g
+    for rnd in range(12):
+        for name, g in dev_specs.items():
+            if rnd % 4 == 3:
+                g.ws.fill_(float("nan"))
+            out = hip_backend.tapgemm(g).clone()
+            if rnd == 0:
+                first[name] = out
+                ref = kc.EMU.tapgemm(specs[name])
+                st = kc.stats(out, ref)
+                tol = kc.TOL32 if g.out_dtype == torch.float32 else kc.TOL16_EMU[dtname]
+                assert st["finite"] and st["rel_l2"] <= tol, (name, st)
+            else:
+                assert torch.equal(out, first[name]), (name, rnd)
+
+
 _TGDW = sorted(kc.tapgemm_dw_cases(torch.bfloat16))
 
 

@@ -217,7 +217,41 @@ class HipBackend:
         return y
 
     # -- tap GEMM --------------------------------------------------------------------------
+    def tapgemm_plan(self, g: TapGemm):
+        """(block shape, BN, split-K) vgen_tapgemm would launch `g` with (vgen_tapgemm_query_plan); no launch."""
+        a = self._tapgemm_args(g)[0]
+        pl = (C.c_int32 * 3)()
+        _lib.check(self.lib.vgen_tapgemm_query_plan(C.byref(a), pl), "vgen_tapgemm_query_plan")
+        return tuple(pl)
+
     def tapgemm(self, g: TapGemm):
+        a, out, cs, A, W, dw, K, n_out, _keep = self._tapgemm_args(g)
+        meta = (g.mode, g.M, g.N, K, g.epilogue, str(g.out_dtype) + ("+dw" if dw is not None else ""))
+        if KERNEL_PROFILE is not None and PROFILE_PLANS:
+            # full launch signature of the plan table + the plan make_plan picks for it (tools/autotune_gemm.py)
+            pl = (C.c_int32 * 3)()
+            self.lib.vgen_tapgemm_query_plan(C.byref(a), pl)
+            flags = (1 if g.residual is not None else 0) | (2 if g.rowbias is not None else 0) | (4 if cs is not None else 0)
+            meta = meta + ((g.mode, g.M, g.N, g.C1, g.C2, g.taps, g.epilogue, _ENUM[g.out_dtype], flags), tuple(pl))
+        # algorithmic FLOP: the product A . W^T with its OWN K (`alg_k`: a two-term activation segment [hi | lo] x [W | W]
+        # executes twice the columns of the product it computes — r03 booked those as algorithmic: VERDICT r03 weak #2);
+        # executed FLOP (extra[1]): 2 M N K_executed, x 2 for a dual-W launch
+        # algorithmic HBM bytes: every distinct operand element once (A's source rows, both weight terms, output, fp32
+        # residual) — what a launch must move if nothing were re-read
+        src_rows = A.shape[0] if g.mode != _lib.TAP_LINEAR else g.M
+        abytes = (2.0 * src_rows * g.C1 + 2.0 * g.M * g.C2 + 2.0 * g.N * K * (2 if dw is not None else 1) +
+                  float(g.M) * n_out * ((4 if g.out_dtype == torch.float32 else 2) + (4 if g.residual is not None else 0)))
+        k_alg = g.alg_k or K
+        assert 0 < k_alg <= K
+        with self._Prof("tapgemm", 2.0 * g.M * g.N * k_alg, meta, (abytes, 2.0 * g.M * g.N * K * (2 if dw is not None else 1))):
+            rc = self.lib.vgen_tapgemm(C.byref(a), self._stream(A))
+        _lib.check(rc, "vgen_tapgemm")
+        if cs is not None:
+            out.vgen_cs = cs
+        return out
+
+    def _tapgemm_args(self, g: TapGemm):
+        """The vgen_tapgemm_args block of `g` (output, column-statistics and split-K workspace allocated here)."""
         A = _mat(g.A, "A")
         dw = getattr(g.W, "vgen_dw", None)          # two-term weight (precision="high"): one dual-W launch
         W = _mat(g.W if dw is None else dw, "W")
@@ -263,35 +297,14 @@ class HipBackend:
             cs = torch.empty(((g.M + CS_ROWS - 1) // CS_ROWS, 2, g.N), dtype=torch.float32, device=A.device)
             a.colstats = cs.data_ptr()
         need = self.lib.vgen_tapgemm_ws_bytes(C.byref(a))
+        ws = g.ws
         if g.ws is not None:
             assert g.ws.is_contiguous() and g.ws.numel() * g.ws.element_size() >= need
             a.ws, a.ws_bytes = g.ws.data_ptr(), g.ws.numel() * g.ws.element_size()
         elif need:
             ws = torch.empty(need // 4, dtype=torch.float32, device=A.device)
             a.ws, a.ws_bytes = ws.data_ptr(), need
-        meta = (g.mode, g.M, g.N, K, g.epilogue, str(g.out_dtype) + ("+dw" if dw is not None else ""))
-        if KERNEL_PROFILE is not None and PROFILE_PLANS:
-            # full launch signature of the plan table + the plan make_plan picks for it (tools/autotune_gemm.py)
-            pl = (C.c_int32 * 3)()
-            self.lib.vgen_tapgemm_query_plan(C.byref(a), pl)
-            flags = (1 if g.residual is not None else 0) | (2 if g.rowbias is not None else 0) | (4 if cs is not None else 0)
-            meta = meta + ((g.mode, g.M, g.N, g.C1, g.C2, g.taps, g.epilogue, _ENUM[g.out_dtype], flags), tuple(pl))
-        # algorithmic FLOP: the product A . W^T with its OWN K (`alg_k`: a two-term activation segment [hi | lo] x [W | W]
-        # executes twice the columns of the product it computes — r03 booked those as algorithmic: VERDICT r03 weak #2);
-        # executed FLOP (extra[1]): 2 M N K_executed, x 2 for a dual-W launch
-        # algorithmic HBM bytes: every distinct operand element once (A's source rows, both weight terms, output, fp32
-        # residual) — what a launch must move if nothing were re-read
-        src_rows = A.shape[0] if g.mode != _lib.TAP_LINEAR else g.M
-        abytes = (2.0 * src_rows * g.C1 + 2.0 * g.M * g.C2 + 2.0 * g.N * K * (2 if dw is not None else 1) +
-                  float(g.M) * n_out * ((4 if g.out_dtype == torch.float32 else 2) + (4 if g.residual is not None else 0)))
-        k_alg = g.alg_k or K
-        assert 0 < k_alg <= K
-        with self._Prof("tapgemm", 2.0 * g.M * g.N * k_alg, meta, (abytes, 2.0 * g.M * g.N * K * (2 if dw is not None else 1))):
-            rc = self.lib.vgen_tapgemm(C.byref(a), self._stream(A))
-        _lib.check(rc, "vgen_tapgemm")
-        if cs is not None:
-            out.vgen_cs = cs
-        return out
+        return a, out, cs, A, W, dw, K, n_out, ws
 
     # -- attention -------------------------------------------------------------------------
     def attention(self, g: Attn):
