@@ -8,8 +8,12 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/evidence
 mkdir -p $O
 cd $R
-timeout 1200 python -m pytest tests -q -m gpu -p no:cacheprovider --maxfail=8 > $O/pytest_gpu.log 2>&1; tail -4 $O/pytest_gpu.log
-cp gpurun_out/parity.json $O/parity.json 2>/dev/null
+# SKIP_SUITE=1 / SKIP_PARTITION=1: a short evidence call (bench line, kernel stats, counters) when the GPU budget does not
+# hold the 11-minute suite again — the driver runs it at round end either way
+if [ -z "${SKIP_SUITE:-}" ]; then
+  timeout 1200 python -m pytest tests -q -m gpu -p no:cacheprovider --maxfail=8 > $O/pytest_gpu.log 2>&1; tail -4 $O/pytest_gpu.log
+  cp gpurun_out/parity.json $O/parity.json 2>/dev/null
+fi
 timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -4 $O/smoke.log
 cd /tmp && export TMPDIR=/tmp
 PREC=${PREC:-mixed}
@@ -17,6 +21,7 @@ B="python $R/bench.py --precision $PREC --no-graph --no-cpu-baseline --no-vae --
 timeout 600 python $R/bench.py --steps 20 --warmup 5 --dump-shapes > $O/bench.json 2> $O/bench.err
 cp $R/gpurun_out/tapgemm_shapes_t2v_fp16_mixed.json $R/gpurun_out/other_shapes_t2v_fp16_mixed.json $O/ 2>/dev/null
 tail -c 1500 $O/bench.json
+if [ -z "${SKIP_PARTITION:-}" ]; then
 P="--steps 20 --warmup 5 --no-cpu-baseline --no-vae --no-roofline --no-e2e --no-parity --no-scaling-model --variants= --partition"
 timeout 200 python $R/bench.py $P > $O/bench_partition_eager.json 2> $O/bench_partition_eager.err
 VGEN_FORCE_COLLECTIVE=1 timeout 200 python $R/bench.py $P > $O/bench_partition_eager_rccl.json 2> $O/bench_partition_eager_rccl.err
@@ -33,6 +38,7 @@ PY
 VGEN_BENCH_ONE_DEVICE=1 timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
   $R/bench.py --gpus 2 --backend gloo --steps 6 --warmup 2 --no-cpu-baseline --no-vae --no-roofline --no-e2e > $O/bench_2ranks_one_device.json 2> $O/bench_2ranks_one_device.err
 tail -c 600 $O/bench_2ranks_one_device.json; tail -2 $O/bench_2ranks_one_device.err
+fi
 rm -rf /tmp/prof_kt
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- $B --steps 5 --warmup 2 > $O/prof_bench.json 2> /dev/null
 python $R/tools/rocprof_summary.py $(ls /tmp/prof_kt/*/*kernel_stats.csv | head -1) $O/kernel_stats_summary.csv | head -24
