@@ -91,6 +91,28 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// 16-byte accesses that are coherent at system scope by themselves (sc0 sc1: the store writes through this XCD's L2, the
+// load does not take a line this XCD's L2 may still hold from an earlier launch) — the split-K partials.  The first
+// version ordered plain stores / loads with __threadfence(): on this chip an agent-scope release / acquire is
+// buffer_wbl2 + buffer_inv over the XCD's WHOLE L2, issued there by every wave of every block of the launch — the other
+// blocks' operand streams lost their L2 and the step got 13 % slower (profiles/r05m_ab_splitk_fences.jsonl).
+// hipcc does not count inline-asm memory operations: the caller waits (wait_vmcnt<0>) before it relies on them.
+#ifdef VGEN_SK_SC1          // A/B variant (tools/runs/gpu_r5m2.sh): agent scope only
+#define VGEN_SK_SCOPE "sc1"
+#else
+#define VGEN_SK_SCOPE "sc0 sc1"
+#endif
+__device__ __forceinline__ void st16_coherent(float* p, const f32x4& v) {
+  asm volatile("global_store_dwordx4 %0, %1, off " VGEN_SK_SCOPE ::"v"(p), "v"(v) : "memory");
+}
+__device__ __forceinline__ void ld16_coherent(f32x4& v, const float* p) {
+  asm volatile("global_load_dwordx4 %0, %1, off " VGEN_SK_SCOPE : "=v"(v) : "v"(p) : "memory");
+}
+// the loaded registers may be used only behind this: ties the value to the wait, so no use can be scheduled above it
+__device__ __forceinline__ void landed(f32x4& v) {
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)::"memory");
+}
+
 // LDS rows are BK 16-bit elements = CPR 16-byte chunks.  The DMA destination is lane-linear, so the
 // bank swizzle is applied to the per-lane SOURCE chunk and again on the fragment reads.
 //   CPR = 8 (128-B rows): chunk ^ (row & 7)
@@ -627,7 +649,7 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   }
 
   if (splitk > 1) {
-    // raw fp32 partial tile -> workspace [split][M][N]
+    // raw fp32 partial tile -> workspace [split][M][N], written THROUGH the L2 (see st16_coherent)
     const int64_t plane = p.M * (int64_t)p.N;
     float* const wsp = ws + (int64_t)split * plane;
 #pragma unroll
@@ -637,30 +659,29 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
 #pragma unroll
       for (int ni = 0; ni < NF; ++ni) {
         const int n = n0 + wn * WTN + ni * 16 + lq * 4;
-        if (n < p.N) *(f32x4*)(wsp + m * p.N + n) = acc[ni][mi];
+        if (n < p.N) st16_coherent(wsp + m * p.N + n, acc[ni][mi]);
       }
     }
-    // Arrival: every thread releases its partial stores at agent scope (the XCDs' L2s are not coherent with each
-    // other: the fence writes this XCD's dirty lines back), the block draws ONE ticket for its tile; the block that
-    // draws the last one re-zeroes the counter for the next launch, acquires, and reduces — every other block is done.
-    __threadfence();
+    // Arrival: once every thread's partial stores are acknowledged the block draws ONE ticket for its tile (relaxed
+    // agent-scope RMW: no cache-wide operation); the block that draws the last one puts the counter back to zero for the
+    // next launch and reduces — every other block is done.
+    wait_vmcnt<0>();
     __syncthreads();                                  // all waves are past their K loop: the operand ring is idle
     volatile __attribute__((address_space(3))) int* const flag = (volatile __attribute__((address_space(3))) int*)(lptr_t)smem;
     if (tid == 0) {
       unsigned* const cnt = &g_sk_tickets[sk_slot][tile];
-      const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       const bool last = ticket == (unsigned)splitk - 1u;
       if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       flag[0] = last ? 1 : 0;
     }
     __syncthreads();
     if (flag[0] == 0) return;
-    __threadfence();                                  // acquire: the other blocks' partials, not stale cache lines
     // Sum in split order 0 .. splitk-1 from the workspace (this block's own partial included: the order — and with it
     // the result, bit for bit — does not depend on which block arrived last), then fall through to the epilogue;
     // res_folded is false under split-K, so bias / row bias / residual / GEGLU are applied exactly once, there.
-    // One pass per split with every fragment's load in flight together (2 row fragments at a time on the dual shape: its 128-row wave
-    // tile has no registers for more): `splitk` L2 / MALL round trips in all, not one per fragment.
+    // One pass per split with every fragment's load in flight together (2 row fragments at a time on the dual shape:
+    // its 128-row wave tile has no registers for more): `splitk` round trips in all, not one per fragment.
 #pragma unroll
     for (int ni = 0; ni < NF; ++ni)
 #pragma unroll
@@ -677,13 +698,17 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
 #pragma unroll
           for (int ni = 0; ni < NF; ++ni) {
             const int n = n0 + wn * WTN + ni * 16 + lq * 4;
-            part[ni][mi] = (m < p.M && n < p.N) ? *(const f32x4*)(src + m * p.N + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            part[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (m < p.M && n < p.N) ld16_coherent(part[ni][mi], src + m * p.N + n);
           }
         }
 #pragma unroll
         for (int mi = 0; mi < MCH; ++mi)
 #pragma unroll
-          for (int ni = 0; ni < NF; ++ni) acc[ni][mc + mi] += part[ni][mi];
+          for (int ni = 0; ni < NF; ++ni) {
+            landed(part[ni][mi]);
+            acc[ni][mc + mi] += part[ni][mi];
+          }
       }
     }
   }
