@@ -187,12 +187,7 @@ typedef struct vgen_tapgemm_args {
 /* Launches whose tile count cannot fill the 256 CUs (small M: the 4x7 / 8x14 UNet levels) are
  * split along K; the partial fp32 tiles need `vgen_tapgemm_ws_bytes(args)` bytes of caller
  * scratch (0 = no split for this shape).  Without a large enough `ws` the call still succeeds
- * unsplit.  The partials are summed inside the same launch — by whichever block of a tile arrives
- * last (one agent-scope ticket per tile, library-owned counters that return to zero), in split
- * order — so results are deterministic and there is no second launch.  The counters are keyed by
- * the stream a launch is issued (or captured) on: launches that may overlap must sit on different
- * streams (they then use different counter sets, up to a collision of a 6-bit hash of the handle);
- * one graph captured once and replayed concurrently with itself is not supported. */
+ * unsplit.  The reduction order is fixed, so results are deterministic. */
 size_t vgen_tapgemm_ws_bytes(const vgen_tapgemm_args* args);
 int vgen_tapgemm(const vgen_tapgemm_args* args, void* stream);
 

@@ -51,12 +51,14 @@ def test_tapgemm(hip_backend, dtname, name):
 
 
 @pytest.mark.parametrize("dtname", ["bf16", "fp16"])
-def test_splitk_reduces_inside_the_launch(hip_backend, dtname):
-    """r05: the partial tiles of a split-K launch are summed by the last block of each tile to arrive (one agent-scope
-    ticket per tile, csrc/tapgemm.hip) — no reducer launch.  Every split launch of the list is issued 12 times, interleaved
-    with the others on one stream (the tickets must be back at zero after every launch, whichever block drew the last one)
-    into a workspace pre-filled with NaN (a partial read before its writer released it, or a stale line, would surface):
-    each output must match the emulator and be BIT-identical to the first run of the same launch."""
+def test_splitk_launches_are_repeatable(hip_backend, dtname):
+    """Split-K launches (partial fp32 tiles to a caller workspace, `splitk_reduce_kernel` sums them in split order and
+    applies the epilogue): every split launch of the list — the planner's own picks, incl. the 4 x 7 level of the
+    benchmark step at its own shapes — is issued 12 times, interleaved with the others on one stream, into a workspace
+    pre-filled with NaN (an element the main kernel did not write, or a reducer that ran ahead of it, would surface): each
+    output must match the emulator and be BIT-identical to the first run of the same launch.  (r05 built the reduction
+    into the main kernel — last block of a tile to arrive — and ran exactly this test on it: csrc/tapgemm.hip, the note
+    above splitk_reduce_kernel, has what that measured and why the second launch stayed.)"""
     dt = kc.DTS[dtname]
     specs = kc.splitk_specs(dt)
     dev_specs, first = {}, {}

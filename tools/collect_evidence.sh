@@ -14,7 +14,7 @@ if [ -z "${SKIP_SUITE:-}" ]; then
   timeout 1200 python -m pytest tests -q -m gpu -p no:cacheprovider --maxfail=8 > $O/pytest_gpu.log 2>&1; tail -4 $O/pytest_gpu.log
   cp gpurun_out/parity.json $O/parity.json 2>/dev/null
 fi
-timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -4 $O/smoke.log
+if [ -z "${SKIP_SMOKE:-}" ]; then timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -4 $O/smoke.log; fi
 cd /tmp && export TMPDIR=/tmp
 PREC=${PREC:-mixed}
 B="python $R/bench.py --precision $PREC --no-graph --no-cpu-baseline --no-vae --no-roofline --no-e2e --no-parity --no-scaling-model --variants="
@@ -43,12 +43,15 @@ rm -rf /tmp/prof_kt
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- $B --steps 5 --warmup 2 > $O/prof_bench.json 2> /dev/null
 python $R/tools/rocprof_summary.py $(ls /tmp/prof_kt/*/*kernel_stats.csv | head -1) $O/kernel_stats_summary.csv | head -24
 SPECS=""
-for c in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY"; do
+# PMC_PASSES=3 drops the wave-cycle pass (the traffic and MFMA-busy figures the bench line quotes need the first three)
+PASSES=("FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE" "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY")
+for c in "${PASSES[@]:0:${PMC_PASSES:-4}}"; do
   tag=$(echo $c | cut -d' ' -f1)
   rm -rf /tmp/prof_$tag
   timeout 400 rocprofv3 --pmc $c --output-format csv -d /tmp/prof_$tag -- $B --steps 1 --warmup 1 > /dev/null 2>&1
   f=$(ls /tmp/prof_$tag/*/*counter_collection.csv 2>/dev/null | head -1)
   if [ -n "$f" ]; then SPECS="$SPECS $tag=$f"; else echo "no counter file for $c"; fi
+  python $R/tools/pmc_classes.py $O/pmc_classes.json $SPECS > /dev/null    # after every pass: a call cut short keeps what it has
 done
 python $R/tools/pmc_classes.py $O/pmc_classes.json $SPECS | head -40
 echo EVIDENCE_DONE

@@ -30,10 +30,8 @@
 //   * XCD-aware tile order: block b runs on XCD b % 8; tiles are renumbered so that each XCD works
 //     on a contiguous run of tiles (same A rows, consecutive W panels) -> its private L2 sees reuse.
 //   * split-K for launches with too few tiles to fill 256 CUs (the 4x7 / 8x14 levels of the UNet):
-//     partial fp32 tiles go to a caller workspace; the LAST block of a tile to arrive (one agent-scope
-//     ticket per tile) sums the partials in split order — fixed, so deterministic whichever block
-//     that is — and runs the ordinary epilogue.  (r01-r04: a second `splitk_reduce_kernel` launch, 56
-//     of them per denoise step.)
+//     partial fp32 tiles go to a caller workspace and a small second kernel reduces them in a
+//     fixed order (deterministic) and applies the epilogue.
 //   * fp32 accumulate; epilogue in fp32: + bias + per-image row-bias (time embedding)
 //     + fp32 residual, optional GEGLU gate, fp32 or 16-bit store, optional per-64-row-slab column
 //     statistics for the GroupNorm that consumes the output.
@@ -91,28 +89,6 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// 16-byte accesses that are coherent at system scope by themselves (sc0 sc1: the store writes through this XCD's L2, the
-// load does not take a line this XCD's L2 may still hold from an earlier launch) — the split-K partials.  The first
-// version ordered plain stores / loads with __threadfence(): on this chip an agent-scope release / acquire is
-// buffer_wbl2 + buffer_inv over the XCD's WHOLE L2, issued there by every wave of every block of the launch — the other
-// blocks' operand streams lost their L2 and the step got 13 % slower (profiles/r05m_ab_splitk_fences.jsonl).
-// hipcc does not count inline-asm memory operations: the caller waits (wait_vmcnt<0>) before it relies on them.
-#ifdef VGEN_SK_SC1          // A/B variant (tools/runs/gpu_r5m2.sh): agent scope only
-#define VGEN_SK_SCOPE "sc1"
-#else
-#define VGEN_SK_SCOPE "sc0 sc1"
-#endif
-__device__ __forceinline__ void st16_coherent(float* p, const f32x4& v) {
-  asm volatile("global_store_dwordx4 %0, %1, off " VGEN_SK_SCOPE ::"v"(p), "v"(v) : "memory");
-}
-__device__ __forceinline__ void ld16_coherent(f32x4& v, const float* p) {
-  asm volatile("global_load_dwordx4 %0, %1, off " VGEN_SK_SCOPE : "=v"(v) : "v"(p) : "memory");
-}
-// the loaded registers may be used only behind this: ties the value to the wait, so no use can be scheduled above it
-__device__ __forceinline__ void landed(f32x4& v) {
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)::"memory");
-}
-
 // LDS rows are BK 16-bit elements = CPR 16-byte chunks.  The DMA destination is lane-linear, so the
 // bank swizzle is applied to the per-lane SOURCE chunk and again on the fragment reads.
 //   CPR = 8 (128-B rows): chunk ^ (row & 7)
@@ -143,18 +119,9 @@ __device__ __forceinline__ int swz_key(int row) {
 // (A + W_hi), the odd step that follows stages and reads only the W_lo tile and multiplies it with the A fragments
 // still sitting in registers.  r02 ran this product as a K-doubled launch ([A | A] x [W_hi | W_lo], every A tile
 // gathered, DMA'd and ds_read twice) or, for tap gathers, as two launches through an fp32 temporary.
-// Arrival tickets of the split-K launches: one counter per output tile, zero between launches (the block that draws
-// the last ticket of a tile puts it back to zero).  SK_SLOTS independent sets, keyed by the stream a launch is issued
-// (or captured) on: launches of one stream are ordered, so they can share a set; launches that may overlap sit on
-// different streams and (up to a hash collision among SK_SLOTS) on different sets.  A launch with more than
-// SK_MAX_TILES tiles is not split (launch()).
-constexpr int SK_SLOTS = 64;
-constexpr int SK_MAX_TILES = 2048;
-__device__ unsigned g_sk_tickets[SK_SLOTS][SK_MAX_TILES];
-
 template <typename T, int BM, int BN, int BK, int WM, int WN, int STAGES, bool PP, bool DW>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_kernel(
-    const vgen_tapgemm_args p, const int splitk, float* ws, const int sk_slot, const int ablate_arg) {
+    const vgen_tapgemm_args p, const int splitk, float* __restrict__ ws, const int ablate_arg) {
   static_assert(!PP || (WM * WN == 8 && STAGES == 3), "ping-pong needs 8 waves and a 3-stage ring");
   static_assert(!DW || (PP && BK == 64), "dual-W K-steps are built on the ping-pong schedule, 64-element K-tiles");
   const int ablate = VGEN_ABLATE_ARG(ablate_arg);
@@ -648,10 +615,8 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
     }
   }
 
-  if (splitk > 1) {
-    // raw fp32 partial tile -> workspace [split][M][N], written THROUGH the L2 (see st16_coherent)
-    const int64_t plane = p.M * (int64_t)p.N;
-    float* const wsp = ws + (int64_t)split * plane;
+  if (splitk > 1) {   // raw fp32 partial tile -> workspace [split][M][N]; epilogue in the reducer
+    float* const wsp = ws + (int64_t)split * p.M * p.N;
 #pragma unroll
     for (int mi = 0; mi < MF; ++mi) {
       const int64_t m = m0 + wm * WTM + mi * 16 + lr;
@@ -659,58 +624,10 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
 #pragma unroll
       for (int ni = 0; ni < NF; ++ni) {
         const int n = n0 + wn * WTN + ni * 16 + lq * 4;
-        if (n < p.N) st16_coherent(wsp + m * p.N + n, acc[ni][mi]);
+        if (n < p.N) *(f32x4*)(wsp + m * p.N + n) = acc[ni][mi];
       }
     }
-    // Arrival: once every thread's partial stores are acknowledged the block draws ONE ticket for its tile (relaxed
-    // agent-scope RMW: no cache-wide operation); the block that draws the last one puts the counter back to zero for the
-    // next launch and reduces — every other block is done.
-    wait_vmcnt<0>();
-    __syncthreads();                                  // all waves are past their K loop: the operand ring is idle
-    volatile __attribute__((address_space(3))) int* const flag = (volatile __attribute__((address_space(3))) int*)(lptr_t)smem;
-    if (tid == 0) {
-      unsigned* const cnt = &g_sk_tickets[sk_slot][tile];
-      const unsigned ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const bool last = ticket == (unsigned)splitk - 1u;
-      if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      flag[0] = last ? 1 : 0;
-    }
-    __syncthreads();
-    if (flag[0] == 0) return;
-    // Sum in split order 0 .. splitk-1 from the workspace (this block's own partial included: the order — and with it
-    // the result, bit for bit — does not depend on which block arrived last), then fall through to the epilogue;
-    // res_folded is false under split-K, so bias / row bias / residual / GEGLU are applied exactly once, there.
-    // One pass per split with every fragment's load in flight together (2 row fragments at a time on the dual shape:
-    // its 128-row wave tile has no registers for more): `splitk` round trips in all, not one per fragment.
-#pragma unroll
-    for (int ni = 0; ni < NF; ++ni)
-#pragma unroll
-      for (int mi = 0; mi < MF; ++mi) acc[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-    constexpr int MCH = MF > 4 ? 2 : MF;
-#pragma unroll
-    for (int mc = 0; mc < MF; mc += MCH) {
-      for (int sp = 0; sp < splitk; ++sp) {
-        const float* const src = ws + sp * plane;
-        f32x4 part[NF][MCH];
-#pragma unroll
-        for (int mi = 0; mi < MCH; ++mi) {
-          const int64_t m = m0 + wm * WTM + (mc + mi) * 16 + lr;
-#pragma unroll
-          for (int ni = 0; ni < NF; ++ni) {
-            const int n = n0 + wn * WTN + ni * 16 + lq * 4;
-            part[ni][mi] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (m < p.M && n < p.N) ld16_coherent(part[ni][mi], src + m * p.N + n);
-          }
-        }
-#pragma unroll
-        for (int mi = 0; mi < MCH; ++mi)
-#pragma unroll
-          for (int ni = 0; ni < NF; ++ni) {
-            landed(part[ni][mi]);
-            acc[ni][mc + mi] += part[ni][mi];
-          }
-      }
-    }
+    return;
   }
 
   // ---- epilogue -------------------------------------------------------------------------
@@ -943,6 +860,56 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
   }
 }
 
+// split-K reducer: fixed summation order over the splits, then the same epilogue as the main kernel.
+// Why this is still a second launch (56 per denoise step, ~7 us each) — r05 built the reduction INTO the main kernel
+// twice ("a split-K whose last-arriving block reduces in-kernel"; commits 4c202c3 and the one after):
+//   v1  every thread __threadfence()s its partial stores, the block draws one agent-scope ticket per tile, the block
+//       with the last ticket __threadfence()s again, sums the partials in split order and runs the ordinary epilogue.
+//       Correct (150 tap-GEMM parity cases, forced dual-shape splits, 12-round repeat test, model-level tests all green,
+//       profiles/r05m_pytest_tapgemm.log) and 13 % SLOWER on the whole step, 33.4 -> 37.7 ms
+//       (profiles/r05m_ab_splitk_fences.jsonl): on gfx950 an agent-scope release / acquire is `buffer_wbl2 sc1` +
+//       `buffer_inv sc1` — a write-back and an invalidate of the XCD's WHOLE 4 MB L2 — issued by every wave of every
+//       block; the blocks still in their K loops lose their operand lines each time.
+//   v2  no fences: partials stored / loaded by inline-asm `global_store/load_dwordx4 ... sc0 sc1` (or `sc1`), s_waitcnt
+//       vmcnt(0) + barrier before a relaxed ticket.  WRONG — 15 of 16 split-K cases off by 3e-3 .. 7e-3 (stale or
+//       not-yet-visible partial lines: the scope bits alone do not order a 16-byte data store against another XCD's
+//       later load on this part; profiles/r05m2_pytest_splitk_scope_bits_FAILED.log) — and still +1.4 % on the step
+//       (33.38 -> 33.85 ms, profiles/r05m2_ab_splitk_scope_bits.jsonl): one block per tile walking `splitk` dependent
+//       round trips at the launch's tail costs more than a chip-wide reducer launch behind a kernel boundary, which
+//       does the cache maintenance ONCE.
+// Both removed; the tests they were run on stayed (tests/test_gpu_kernels.py::test_splitk_launches_are_repeatable).
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const vgen_tapgemm_args p, const int splitk,
+                                                            const float* __restrict__ ws) {
+  const bool geglu = p.epilogue == VGEN_EPI_GEGLU;
+  const int n_out = geglu ? p.N / 2 : p.N;
+  const int ng = n_out >> 2;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.M * ng) return;
+  const int64_t m = idx / ng;
+  const int j = (int)(idx - m * ng) * 4;
+  const int64_t plane = p.M * (int64_t)p.N;
+  const int pn = geglu ? 32 * (j >> 4) + (j & 15) : j;
+  f32x4 v = {0, 0, 0, 0}, gt = {0, 0, 0, 0};
+  for (int s = 0; s < splitk; ++s) {
+    v += *(const f32x4*)(ws + s * plane + m * p.N + pn);
+    if (geglu) gt += *(const f32x4*)(ws + s * plane + m * p.N + pn + 16);
+  }
+  if (p.bias) {
+    v += *(const f32x4*)(p.bias + pn);
+    if (geglu) gt += *(const f32x4*)(p.bias + pn + 16);
+  }
+  if (geglu) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = v[r] * gelu_erf_f(gt[r]);
+  } else if (p.rowbias) {
+    v += *(const f32x4*)(p.rowbias + (m / p.rows_per_rb) * p.rowbias_ld + j);
+  }
+  if (p.residual) v += *(const f32x4*)(p.residual + m * p.ldr + j);
+  if (p.out_dtype == VGEN_F32) *(f32x4*)((float*)p.out + m * p.ldo + j) = v;
+  else *(u32x2*)((uint16_t*)p.out + m * p.ldo + j) = pack4<T>(v.x, v.y, v.z, v.w);
+}
+
 // ---- launch planning ---------------------------------------------------------------------------
 // 256-row tiles make tile-count quantisation expensive (280 tiles on 256 CUs = 2 rounds at 55 %
 // fill), so the block shape, the column tile BN and the split-K factor are chosen together from a
@@ -1003,11 +970,6 @@ Plan make_plan(const vgen_tapgemm_args& a) {
   constexpr int force_shape = -1;
 #endif
   const int smax = (vec && a.colstats == nullptr && !a.split_out) ? (KT / 4 < 32 ? KT / 4 : 32) : 1;
-#ifdef VGEN_TUNING
-  static const double sk_fixed_us = getenv("VGEN_SK_FIXED_US") ? atof(getenv("VGEN_SK_FIXED_US")) : 5.0;
-#else
-  constexpr double sk_fixed_us = 5.0;
-#endif
   // HBM time of the epilogue traffic (output + fp32 residual), not hidden behind MFMAs when every CU
   // runs one block in the same phase ("pp"); about half hidden with two independent blocks per CU
   const double epi_us = (double)a.M * n_out * ((a.out_dtype == VGEN_F32 ? 4 : 2) + (a.residual ? 4 : 0)) / 4.5e6;
@@ -1074,9 +1036,7 @@ Plan make_plan(const vgen_tapgemm_args& a) {
         } else {
           cost = (double)((blocks + 511) / 512) * (kts * t_d2[bi] + 9.0) + 0.5 * epi_us + 1.0;
         }
-        // split-K: the partials' round trip at ~3 TB/s + a fixed cost (r01-r04: the reducer's launch; r05: the last
-        // block's ticket and its `s` dependent partial loads)
-        if (s > 1) cost += sk_fixed_us + (double)(s + 1) * a.M * a.N * 4.0 / 3.0e6;
+        if (s > 1) cost += 5.0 + (double)(s + 1) * a.M * a.N * 4.0 / 3.0e6;   // partials at ~3 TB/s
         if (cost < best_cost - 1e-9) {
           best_cost = cost;
           best = Plan{shape, bn, s};
@@ -1109,10 +1069,8 @@ int launch(const vgen_tapgemm_args& a, int splitk, hipStream_t stream) {
     vgen_set_error("tapgemm: grid too large");
     return VGEN_E_BADARG;
   }
-  if (splitk > 1 && (a.ws == nullptr || a.ws_bytes < (size_t)splitk * a.M * a.N * sizeof(float) || grid > SK_MAX_TILES))
-    splitk = 1;   // caller did not provide the workspace (or more tiles than tickets): still correct, just fewer blocks
-  const int sk_slot = (int)((((uint64_t)(uintptr_t)stream >> 4) * 0x9E3779B97F4A7C15ull) >> 58);   // 6 bits: SK_SLOTS
-  static_assert(SK_SLOTS == 64, "sk_slot is a 6-bit hash");
+  if (splitk > 1 && (a.ws == nullptr || a.ws_bytes < (size_t)splitk * a.M * a.N * sizeof(float)))
+    splitk = 1;   // caller did not provide the workspace: still correct, just fewer blocks
 #ifdef VGEN_TUNING
   const char* ab = getenv("VGEN_TAPGEMM_ABLATE");
   const int ablate = ab ? atoi(ab) : 0;
@@ -1120,8 +1078,14 @@ int launch(const vgen_tapgemm_args& a, int splitk, hipStream_t stream) {
   const int ablate = 0;
 #endif
   hipLaunchKernelGGL((tapgemm_kernel<T, BM, BN, BK, WM, WN, STAGES, PP, DW>), dim3((unsigned)grid, (unsigned)splitk),
-                     dim3(WM * WN * 64), lds, stream, a, splitk, (float*)a.ws, sk_slot, ablate);
-  return vgen_check_launch("tapgemm");
+                     dim3(WM * WN * 64), lds, stream, a, splitk, (float*)a.ws, ablate);
+  int rc = vgen_check_launch("tapgemm");
+  if (rc || splitk == 1) return rc;
+  const int n_out = a.epilogue == VGEN_EPI_GEGLU ? a.N / 2 : a.N;
+  const int64_t threads = a.M * (n_out / 4);
+  hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                     stream, a, splitk, (const float*)a.ws);
+  return vgen_check_launch("tapgemm(splitk reduce)");
 }
 
 // the panel shape is asked first: a launch it takes is never planned on a streaming shape (tuning build:
