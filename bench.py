@@ -775,7 +775,7 @@ def main():
                                        "beside 1.28 k cycles of MFMAs; stamped K-step 2.0 k cycles (DESIGN 3.1)"}}
         # HBM-side bytes per launch cannot be read from inside the process: they come from committed rocprofv3 PMC
         # passes of this command (tools/collect_evidence.sh -> profiles/) and are labelled as such
-        for tname in ("r05_tapgemm_traffic.json", "r04_tapgemm_traffic.json", "r03_tapgemm_traffic.json", "r02_tapgemm_traffic.json"):
+        for tname in ("r05n_tapgemm_traffic.json", "r05_tapgemm_traffic.json", "r04_tapgemm_traffic.json", "r03_tapgemm_traffic.json", "r02_tapgemm_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", tname)
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
