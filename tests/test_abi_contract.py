@@ -297,7 +297,7 @@ def test_splitk_parity_cases_really_split():
         for name, spec in kc.splitk_specs(dt).items():
             shape, bn, sk = be.tapgemm_plan(spec)
             assert shape in (SHAPE_PP, SHAPE_DUAL, SHAPE_PP128) and sk > 1, (name, shape, bn, sk)
-            a = be._tapgemm_args(spec)
-            assert a[0].ws_bytes == sk * spec.M * spec.N * 4 and a[-1] is not None, (name, sk, a[0].ws_bytes)
+            a = be._tapgemm_args(spec, alloc=False)
+            assert a[0].ws_bytes == sk * spec.M * spec.N * 4 and a[1] is None and a[-1] is None, (name, sk, a[0].ws_bytes)
             tiles = -(-spec.M // (128 if shape == SHAPE_PP128 else 256)) * -(-spec.N // bn)
             assert tiles * sk <= 512, (name, tiles, sk)  # split-K exists to FILL the chip, not to oversubscribe it

@@ -218,8 +218,9 @@ class HipBackend:
 
     # -- tap GEMM --------------------------------------------------------------------------
     def tapgemm_plan(self, g: TapGemm):
-        """(block shape, BN, split-K) vgen_tapgemm would launch `g` with (vgen_tapgemm_query_plan); no launch."""
-        a = self._tapgemm_args(g)[0]
+        """(block shape, BN, split-K) vgen_tapgemm would launch `g` with (vgen_tapgemm_query_plan); no launch, nothing
+        allocated (the planner reads sizes, strides and which optional pointers are set, never the operands)."""
+        a = self._tapgemm_args(g, alloc=False)[0]
         pl = (C.c_int32 * 3)()
         _lib.check(self.lib.vgen_tapgemm_query_plan(C.byref(a), pl), "vgen_tapgemm_query_plan")
         return tuple(pl)
@@ -250,8 +251,11 @@ class HipBackend:
             out.vgen_cs = cs
         return out
 
-    def _tapgemm_args(self, g: TapGemm):
-        """The vgen_tapgemm_args block of `g` (output, column-statistics and split-K workspace allocated here)."""
+    _PLAN_ONLY = 0x1000   # stand-in for the buffers a plan query does not allocate (16-byte aligned, never dereferenced)
+
+    def _tapgemm_args(self, g: TapGemm, alloc: bool = True):
+        """The vgen_tapgemm_args block of `g` (output, column-statistics and split-K workspace allocated here unless
+        alloc=False: the plan query)."""
         A = _mat(g.A, "A")
         dw = getattr(g.W, "vgen_dw", None)          # two-term weight (precision="high"): one dual-W launch
         W = _mat(g.W if dw is None else dw, "W")
@@ -259,10 +263,11 @@ class HipBackend:
         n_out = g.N // 2 if g.epilogue == _lib.EPI_GEGLU else g.N
         out = g.out
         w_out = 2 * n_out if g.split_out else n_out
-        if out is None:
+        if out is None and alloc:
             out = torch.empty((g.M, w_out), dtype=g.out_dtype, device=A.device)
-        _mat(out, "out")
-        assert out.dtype == g.out_dtype and out.shape[0] == g.M and out.shape[1] >= w_out
+        if out is not None:
+            _mat(out, "out")
+            assert out.dtype == g.out_dtype and out.shape[0] == g.M and out.shape[1] >= w_out
         a = _lib.TapGemmArgs()
         a.M, a.N, a.dtype = g.M, g.N, _ENUM[A.dtype]
         a.A, a.lda, a.C1, a.taps, a.mode = A.data_ptr(), A.stride(0), g.C1, g.taps, g.mode
@@ -290,20 +295,23 @@ class HipBackend:
             r = _mat(g.residual, "residual")
             assert r.dtype == torch.float32 and r.shape[0] == g.M
             a.residual, a.ldr = r.data_ptr(), r.stride(0)
-        a.out, a.ldo, a.out_dtype, a.epilogue = out.data_ptr(), out.stride(0), _ENUM[g.out_dtype], g.epilogue
+        a.out, a.ldo = (out.data_ptr(), out.stride(0)) if out is not None else (self._PLAN_ONLY, w_out)
+        a.out_dtype, a.epilogue = _ENUM[g.out_dtype], g.epilogue
         a.split_out = int(bool(g.split_out))
         cs = None
         if g.colstats and _COLSTATS_ON:
-            cs = torch.empty(((g.M + CS_ROWS - 1) // CS_ROWS, 2, g.N), dtype=torch.float32, device=A.device)
-            a.colstats = cs.data_ptr()
+            if alloc:
+                cs = torch.empty(((g.M + CS_ROWS - 1) // CS_ROWS, 2, g.N), dtype=torch.float32, device=A.device)
+            a.colstats = cs.data_ptr() if alloc else self._PLAN_ONLY
         need = self.lib.vgen_tapgemm_ws_bytes(C.byref(a))
         ws = g.ws
         if g.ws is not None:
             assert g.ws.is_contiguous() and g.ws.numel() * g.ws.element_size() >= need
             a.ws, a.ws_bytes = g.ws.data_ptr(), g.ws.numel() * g.ws.element_size()
         elif need:
-            ws = torch.empty(need // 4, dtype=torch.float32, device=A.device)
-            a.ws, a.ws_bytes = ws.data_ptr(), need
+            if alloc:
+                ws = torch.empty(need // 4, dtype=torch.float32, device=A.device)
+            a.ws, a.ws_bytes = (ws.data_ptr() if alloc else self._PLAN_ONLY), need
         return a, out, cs, A, W, dw, K, n_out, ws
 
     # -- attention -------------------------------------------------------------------------
