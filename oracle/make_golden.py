@@ -323,6 +323,36 @@ def make_i2vgen_full(R):
                os.path.join(GOLD, "unet_i2vgen_full.pt"))
 
 
+def make_i2vgen_full_b(R):
+    """r05 (VERDICT r04 weak #1b: the I2VGen margin rested on ONE (weights, input, t) triple): a second full-width
+    UNetSD_I2VGen fixture at the same real latent [1,4,16,88,160] — heavy-tailed (Student-t, nu = 4) weights of seed 1,
+    another input, t = 301, fps = 16.  Same storage as make_i2vgen_full (output sub-sampled + its norm)."""
+    import time
+    cfg = dict(UNET_T2V, concat_dim=4, upper_len=128, default_fps=8, training=False)      # i2vgen_xl_train.yaml:32-51
+    ref = R["MODEL"].build(dict(type="UNetSD_I2VGen", **cfg)).eval()
+    shapes = torch_ref.shapes_of(ref)
+    ref.load_state_dict(torch_ref.synth_state_dict(shapes, seed=1, recipe="student4"), strict=True)
+    g = torch.Generator("cpu").manual_seed(8894)
+    x = torch.randn(1, 4, 16, 88, 160, generator=g)
+    y = torch.randn(1, 77, 1024, generator=g)
+    image = torch.randn(1, 1, 1024, generator=g)
+    local_image = torch.randn(1, 4, 88, 160, generator=g)
+    fps = torch.tensor([16])
+    t = torch.tensor([301])
+    _cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self           # mask_pos hard-codes .cuda() (unet_i2vgen.py:284)
+    try:
+        with torch.no_grad():
+            t0 = time.time()
+            out = ref(x, t, y=y, image=image, local_image=local_image, fps=fps)
+            print("unet_i2vgen full_b forward: %.1f s, std %.4f" % (time.time() - t0, float(out.std())))
+    finally:
+        torch.Tensor.cuda = _cuda
+    torch.save(dict(cfg=cfg, seed=1, recipe="student4", shapes=shapes, input_seed=8894, t=t, fps=fps,
+                    out_sub=out[:, :, ::2, ::4, ::4].contiguous(), out_norm=float(out.norm())),
+               os.path.join(GOLD, "unet_i2vgen_full_b.pt"))
+
+
 def _sub(out):
     """full-size outputs are stored sub-sampled (frames ::2, rows / cols ::4) with their norm"""
     return out[:, :, ::2, ::4, ::4].contiguous()
@@ -761,6 +791,9 @@ def main():
         return
     if args.only == "i2vgen_full":
         make_i2vgen_full(R)
+        return
+    if args.only == "i2vgen_full_b":
+        make_i2vgen_full_b(R)
         return
     extra = dict(t2v_traj6=make_t2v_traj6, t2v_extra=make_t2v_extra, videolcm_full=make_videolcm_full, tft2v_full=make_tft2v_full,
                  sr600_full=make_sr600_full, vcomposer_full=make_vcomposer_full)

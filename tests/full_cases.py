@@ -10,6 +10,7 @@ fixture (oracle/make_golden.py --only ...)   model / shape                      
   tft2v    unet_tft2v_full.pt    UNetSD_TFT2V ['text','image'] [1,4,16,64,112], t = 401            unet_tf2tv.py:538-777
   sr600    unet_sr600_full.pt    UNetSD_SR600 [1,4,32,90,160], t = 699                              unet_sr600.py:220-299
   i2vgen   unet_i2vgen_full.pt   UNetSD_I2VGen [1,4,16,88,160], t = 601 (r03)                       unet_i2vgen.py:243-262
+  i2vgen_b unet_i2vgen_full_b.pt same, Student-t (nu = 4) weights seed 1, another input, t = 301, fps 16 (r05)
   vcomposer unet_vcomposer_full.pt UNetSD_TFT2V, the 8-entry vcomposer composition list, [1,4,32,64,112] (32 frames 896x512),
                                  six pixel-resolution condition maps regenerated from a seed, t = 601   unet_tf2tv.py:538-777
 """
@@ -23,8 +24,8 @@ from oracle import torch_ref
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 FIX = {"t2v": "unet_t2v_full.pt", "t2v_b": "unet_t2v_full_b.pt", "t2v_c": "unet_t2v_full_c.pt",
        "videolcm": "unet_videolcm_full.pt", "tft2v": "unet_tft2v_full.pt", "sr600": "unet_sr600_full.pt",
-       "i2vgen": "unet_i2vgen_full.pt", "vcomposer": "unet_vcomposer_full.pt"}
-SHAPE = {"tft2v": (1, 4, 16, 64, 112), "sr600": (1, 4, 32, 90, 160), "i2vgen": (1, 4, 16, 88, 160),
+       "i2vgen": "unet_i2vgen_full.pt", "i2vgen_b": "unet_i2vgen_full_b.pt", "vcomposer": "unet_vcomposer_full.pt"}
+SHAPE = {"tft2v": (1, 4, 16, 64, 112), "sr600": (1, 4, 32, 90, 160), "i2vgen": (1, 4, 16, 88, 160), "i2vgen_b": (1, 4, 16, 88, 160),
          "vcomposer": (1, 4, 32, 64, 112)}
 
 
@@ -38,7 +39,7 @@ def build(name, g, precision, dev="cpu", dtname="fp16"):
     from vgen_amd.unet_videolcm import UNetSD_TFT2V, UNetSD_VideoLCM
     kw = dict(g["cfg"])
     cls = {"videolcm": UNetSD_VideoLCM, "tft2v": UNetSD_TFT2V, "vcomposer": UNetSD_TFT2V, "sr600": UNetSD_SR600,
-           "i2vgen": UNetSD_I2VGen}.get(name, UNetSD_T2VBase)
+           "i2vgen": UNetSD_I2VGen, "i2vgen_b": UNetSD_I2VGen}.get(name, UNetSD_T2VBase)
     if name in ("videolcm", "tft2v", "vcomposer"):
         kw["config"] = types.SimpleNamespace(video_compositions=g["comps"], resolution=g["resolution"])
     with torch.device("meta"):
@@ -54,9 +55,9 @@ def inputs(name, g):
     gen = torch.Generator("cpu").manual_seed(g["input_seed"])
     x = torch.randn(*SHAPE.get(name, (1, 4, 16, 32, 56)), generator=gen)
     kw = dict(y=torch.randn(1, 77, 1024, generator=gen))
-    if name in ("tft2v", "i2vgen"):
+    if name in ("tft2v", "i2vgen", "i2vgen_b"):
         kw["image"] = torch.randn(1, 1, 1024, generator=gen)
-    if name == "i2vgen":
+    if name in ("i2vgen", "i2vgen_b"):
         kw["local_image"] = torch.randn(1, 4, 88, 160, generator=gen)
         kw["fps"] = g["fps"]
     if name == "vcomposer":
