@@ -454,7 +454,7 @@ def main():
                          "reference's fp32 forward on the full-width fixtures; high: two-term "
                          "weights everywhere; fast: one 16-bit operand pair per GEMM (the reference's autocast arithmetic; "
                          "1.33e-3); mixed:e0d01t1-style strings select levels (vgen_amd/unet.py)")
-    ap.add_argument("--variants", default="fp16/high,fp16/fast,bf16/fast",
+    ap.add_argument("--variants", default="fp16/high,fp16/fast,bf16/fast,fp16/calibrated",
                     help="other dtype/precision modes timed + parity-checked after the headline mode (t2v, N = 1); '' = none")
     ap.add_argument("--stage1", default="text_image", choices=["text_image", "vcomposer"],
                     help="--config tft2v_sr600: composition list of the first stage (vcomposer = the reference yaml's eight "
@@ -914,7 +914,28 @@ def main():
             vdt, vpr = v.split("/")
             if (vdt, vpr) == (args.dtype, args.precision):
                 continue
-            vm = build_model("t2v", dev, vdt, vpr, state_dict=sd)
+            cal = None
+            if vpr == "calibrated":
+                # r05 (vgen_amd/calibrate.py): every weight SINGLE-PASS, its 16-bit rounding chosen by error feedback from
+                # one calibration forward — on other noise, prompt and timestep than anything timed or parity-checked here.
+                # Pack-time work, reported next to the variant; a failure is reported and never touches the headline.
+                try:
+                    from vgen_amd.calibrate import calibrate_single_pass
+                    vm = build_model("t2v", dev, vdt, "high", state_dict=sd)
+                    cg = torch.Generator(device=dev).manual_seed(424242)
+                    t_c = time.perf_counter()
+                    rep = calibrate_single_pass(vm, torch.randn(1, C, F, H, W, generator=cg, device=dev),
+                                                torch.full((1,), 637, dtype=torch.long, device=dev),
+                                                y=torch.randn(1, 77, 1024, generator=cg, device=dev))
+                    torch.cuda.synchronize()
+                    cal = {"seconds": round(time.perf_counter() - t_c, 1), "weights_calibrated": rep["calibrated"],
+                           "weights_to_nearest": rep["nearest"], "two_term_left": rep["two_term_left"],
+                           "input": "noise / prompt seed 424242, t = 637 (the timed steps and the parity fixtures use others)"}
+                except Exception as exc:                       # noqa: BLE001 — the variant is optional, the line is not
+                    res["variants"][v] = {"failed": f"{type(exc).__name__}: {exc}"[:300]}
+                    continue
+            else:
+                vm = build_model("t2v", dev, vdt, vpr, state_dict=sd)
             drop_masters(vm, dev)
             vd = DiffusionDDIM(**DDIM)
             vd.rng_parity = False
@@ -926,6 +947,13 @@ def main():
             if not args.no_parity:
                 e = golden_parity(vm, gold, dev)
                 ent.update(unet_rel_l2=e, within_tolerance=bool(e <= TOLERANCE))
+                if cal is not None and os.path.exists(GOLDEN_T2V_C):        # the same weights at t = 501, another input
+                    ent["unet_rel_l2_t501"] = golden_parity(vm, torch.load(GOLDEN_T2V_C, map_location="cpu", weights_only=False), dev)
+            if cal is not None:
+                ent["calibration"] = cal
+                ent["note"] = ("precision='high' + vgen_amd.calibrate.calibrate_single_pass: one 16-bit matrix per layer, "
+                               "single-pass launches; first GPU measurement of this mode is the run that printed this line "
+                               "(emulator prediction: profiles/r05_emu_calibrated.txt)")
             res["variants"][v] = ent
             del vm, vd, vt, vx
             gc.collect()

@@ -361,6 +361,8 @@ class UNetSD_T2VBase(nn.Module):
         parameters in place); sampling sessions (vgen_amd/session.py) key on `_epoch`."""
         self._packed = None
         self._epoch = getattr(self, "_epoch", 0) + 1
+        if self.precision == "calibrated":       # vgen_amd/calibrate.py: the calibrated roundings went with the packed
+            self.precision = "high"              # operands; the next pack() is two-term again, ready to be re-calibrated
 
     def _resblocks(self):
         for blk in list(self.input_blocks) + [self.middle_block] + list(self.output_blocks):
