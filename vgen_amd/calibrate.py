@@ -47,9 +47,18 @@ def gptq_round(W: torch.Tensor, H: torch.Tensor, dt, damp: float = 0.01, block: 
     dead = d <= 0                                   # an input column that is identically zero: its weight cannot matter
     H[dead, dead] = 1.0
     W[:, dead] = 0.0
-    H.diagonal().add_(damp * float(d.mean()))
-    Hinv = torch.cholesky_inverse(torch.linalg.cholesky(H))
-    U = torch.linalg.cholesky(Hinv, upper=True).float()       # H^-1 = U^T U; row i of U = how column i's error spreads
+    mean_d = float(d.mean())
+    U = None
+    for attempt in range(3):                        # a numerically singular H: more damping; at worst, to-nearest
+        H.diagonal().add_(damp * (10.0 ** attempt) * mean_d)
+        try:
+            Hinv = torch.cholesky_inverse(torch.linalg.cholesky(H))
+            U = torch.linalg.cholesky(Hinv, upper=True).float()   # H^-1 = U^T U; row i of U = how column i's error spreads
+            break
+        except RuntimeError:                        # torch.linalg.LinAlgError is a RuntimeError
+            continue
+    if U is None or not bool(torch.isfinite(U).all()):
+        return W.to(dt)
     Q = torch.empty_like(W)
     # the column loop is K x ~6 tiny tensor ops: on many threads each costs ~100 us of fork / join (measured on the GPU
     # box: 15 s for the tiny UNet's 240 weights), on one ~15 us; the factorisations above keep the caller's thread count
@@ -115,10 +124,14 @@ class CalibratingBackend:
     """Wraps an op backend: every tap-GEMM launch whose weight is still two-term gets its weight rounded (error feedback
     for K <= k_max, to-nearest above) and converted to single-pass IN PLACE before the launch is forwarded."""
 
-    def __init__(self, inner, damp: float = 0.01, k_max: int = 9000, rows_per_k: int = 4, min_rows: int = 16384):
+    def __init__(self, inner, damp: float = 0.01, k_max: int = 9000, rows_per_k: int = 4, min_rows: int = 16384,
+                 time_budget_s: float = 0.0):
         self.inner = inner
         self.damp, self.k_max, self.rows_per_k, self.min_rows = damp, k_max, rows_per_k, min_rows
-        self.report = dict(calibrated=0, nearest=0, seconds_h=0.0, seconds_round=0.0, max_move=0.0)
+        # time_budget_s > 0: once the pass has spent this long, the remaining weights keep to-nearest rounding (the
+        # forward visits the full-resolution level — where the sensitivity sits — first and last, the cheap K's throughout)
+        self.deadline = time.time() + time_budget_s if time_budget_s > 0 else None
+        self.report = dict(calibrated=0, nearest=0, over_budget=0, seconds_h=0.0, seconds_round=0.0, max_move=0.0)
 
     def __getattr__(self, name):            # every other op: the wrapped backend's
         return getattr(self.inner, name)
@@ -129,7 +142,10 @@ class CalibratingBackend:
             K = g.taps * g.C1 + g.C2
             dt = g.W.dtype
             assert dw.shape[1] == 2 * K and g.W.shape[1] == K and g.W.is_contiguous()
-            if K <= self.k_max and g.M > 0:
+            late = self.deadline is not None and time.time() > self.deadline
+            if late:
+                self.report["over_budget"] += 1
+            if K <= self.k_max and g.M > 0 and not late:
                 t0 = time.time()
                 hi, lo = ops.dw_terms(dw)
                 w32 = hi.float() + lo.float()                                  # the packed fp32 weight to 2^-22
@@ -156,16 +172,17 @@ class CalibratingBackend:
 
 
 @torch.no_grad()
-def calibrate_single_pass(model, x, t, damp: float = 0.01, k_max: int = 9000, **kwargs):
+def calibrate_single_pass(model, x, t, damp: float = 0.01, k_max: int = 9000, time_budget_s: float = 0.0, **kwargs):
     """Turn a model packed with precision="high" into a single-pass model with calibrated roundings, in place.
 
     x, t, **kwargs: one calibration input for model.forward (any noise / timestep / conditioning of the shapes the model
-    will be sampled at).  Returns the report dict of the pass.  Afterwards `model.precision == "calibrated"`; repacking
+    will be sampled at); time_budget_s > 0 bounds the pass (weights reached later keep to-nearest rounding).  Returns the
+    report dict of the pass.  Afterwards `model.precision == "calibrated"`; repacking
     (loading other weights) returns the model to "high"."""
     if getattr(model, "precision", None) != "high":
         raise ValueError(f"calibrate_single_pass needs a model built with precision='high' (every packed weight two-term); "
                          f"got precision={getattr(model, 'precision', None)!r}")
-    cb = CalibratingBackend(ops.backend(), damp=damp, k_max=k_max)
+    cb = CalibratingBackend(ops.backend(), damp=damp, k_max=k_max, time_budget_s=time_budget_s)
     prev = ops.set_backend(cb)
     # host linear algebra: LAPACK on a few tens of threads (on a 256-thread host the default thread count makes it slower)
     import os
