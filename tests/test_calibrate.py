@@ -50,6 +50,51 @@ def test_error_feedback_rounding_beats_to_nearest_on_correlated_inputs():
     assert torch.isfinite(Q.float()).all()
 
 
+def test_host_library_exports_its_header_and_matches_the_torch_loop_bit_for_bit():
+    """libvgen_host.so (csrc/host_round.cpp) = include/vgen_host.h's symbols; its column loop and the torch restatement give
+    the SAME 16-bit matrix (fp16 and bf16, K not a multiple of the block, a dead column, values that need subnormals), and the
+    one-Cholesky inverse factor is the reference recipe's matrix."""
+    import re
+    from conftest import ROOT
+    from vgen_amd import build as b
+    from vgen_amd import calibrate as cal
+    b.build_host()
+    cal._HOST[:] = [None, False]
+    h = cal.host_lib()
+    assert h is not None and h.vgen_host_abi_version() == 1
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "vgen_host.h")).read(), flags=re.S)
+    names = set(re.findall(r"\b(vgen_host_[a-z0-9_]+)\s*\(", src))
+    assert names == {"vgen_host_abi_version", "vgen_host_gptq_block"}
+    for n in names:
+        assert hasattr(h, n), n
+    g = torch.Generator("cpu").manual_seed(11)
+    K, N, M = 300, 70, 1500                                           # 300 = 2 x 128 + 44: a ragged last block
+    A = torch.randn(M, K, generator=g) @ (torch.randn(K, K, generator=g) * 0.1 + torch.eye(K))
+    A[:, 5] = 0
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    W[3] *= 1e-6                                                      # fp16 subnormals
+    W[4] *= 3e4                                                       # large values
+    H = A.t() @ A
+    for dt in (torch.float16, torch.bfloat16):
+        q_host = cal.gptq_round(W, H, dt)
+        q_torch = cal.gptq_round(W, H, dt, use_host_lib=False)
+        assert q_host.dtype == dt and torch.equal(q_host, q_torch), dt
+        assert torch.isfinite(q_host.float()).all()
+    # bad arguments are rejected, not executed
+    z = torch.zeros(4, 256)
+    assert h.vgen_host_gptq_block(z.data_ptr(), 4, 256, z.data_ptr(), 256, 0, 129, 0, z.data_ptr(), 256, z.data_ptr(), 129, 1) == -1
+    assert h.vgen_host_gptq_block(z.data_ptr(), 4, 256, z.data_ptr(), 256, 0, 64, 7, z.data_ptr(), 256, z.data_ptr(), 64, 1) == -1
+    Hd = H.double()
+    Hd[5, 5] = 1.0
+    Hd.diagonal().add_(0.01 * float(Hd.diagonal().mean()))
+    U = cal.inverse_factor(Hd.clone())
+    U_ref = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(Hd)), upper=True)
+    assert float((U - U_ref).abs().max()) <= 1e-10 * float(U_ref.abs().max())
+    assert float((U.t() @ U @ Hd - torch.eye(K, dtype=torch.float64)).abs().max()) < 1e-8
+    bad = torch.zeros(4, 4, dtype=torch.float64)
+    assert cal.inverse_factor(bad) is None
+
+
 def test_gathered_operand_is_the_emulators_a_operand():
     """gathered_operand . W^T == the emulator's tap-GEMM (no bias / epilogue) for a linear, a strided / up-sampled / cropped
     3x3 conv with a skip segment, and a temporal conv — the row gather is the calibration's only knowledge of the tap modes."""

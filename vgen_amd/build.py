@@ -38,6 +38,27 @@ def _stale(target: str, deps) -> bool:
 
 
 TUNING_LIB = os.path.join(HERE, "libvgen_hip_tuning.so")
+HOST_LIB = os.path.join(HERE, "libvgen_host.so")
+# HOST code of the pack-time calibration (csrc/host_round.cpp): plain g++, no device part.  x86-64-v3 = AVX2 + F16C (the
+# fp16 round-to-nearest-even conversion), which every EPYC host of an MI355X has; -ffp-contract=off keeps the loop's
+# arithmetic identical to its torch restatement (no fused multiply-add).
+HOST_FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "-march=x86-64-v3", "-ffp-contract=off", "-Wall", "-pthread"]
+
+
+def build_host(force: bool = False, verbose: bool = False) -> str:
+    """libvgen_host.so next to libvgen_hip.so (git-ignored, travels with the snapshot)."""
+    src = os.path.join(CSRC, "host_round.cpp")
+    if force or _stale(HOST_LIB, [src]):
+        gxx = os.environ.get("CXX") or shutil.which("g++") or shutil.which("c++")
+        if not gxx:
+            raise RuntimeError("g++ not found (need a host C++ compiler to build libvgen_host.so)")
+        cmd = [gxx] + HOST_FLAGS + [src, "-o", HOST_LIB]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("build failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
+    return HOST_LIB
 
 
 def build(force: bool = False, verbose: bool = False, tuning: bool = False, variant: str = "", defines=()) -> str:
@@ -81,3 +102,4 @@ if __name__ == "__main__":
     _var = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("--variant=")), "")
     print(build(force="--force" in sys.argv, verbose=True, tuning="--tuning" in sys.argv, variant=_var,
                 defines=tuple(a[2:] for a in sys.argv if a.startswith("-D"))))
+    print(build_host(force="--force" in sys.argv, verbose=True))

@@ -36,13 +36,80 @@ from . import lib as _lib
 from . import ops
 
 
-def gptq_round(W: torch.Tensor, H: torch.Tensor, dt, damp: float = 0.01, block: int = 128) -> torch.Tensor:
+_HOST = [None, False]                      # [ctypes handle, looked for]
+
+
+def host_lib():
+    """libvgen_host.so (csrc/host_round.cpp, built by vgen_amd.build.build_host with g++): the column loop below as one call
+    per column block, rows over threads.  None when it has not been built — the torch loop is the same arithmetic, ~50x
+    slower on the full-size UNet (it is the tested restatement of the C++ loop, and both are HOST pack-time code)."""
+    if not _HOST[1]:
+        _HOST[1] = True
+        import ctypes
+        import os
+        path = os.environ.get("VGEN_HOST_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvgen_host.so")
+        if os.path.exists(path):
+            h = ctypes.CDLL(path)
+            i64, vp = ctypes.c_int64, ctypes.c_void_p
+            h.vgen_host_gptq_block.argtypes = [vp, i64, i64, vp, i64, i64, i64, ctypes.c_int, vp, i64, vp, i64, ctypes.c_int]
+            h.vgen_host_gptq_block.restype = ctypes.c_int
+            h.vgen_host_abi_version.restype = ctypes.c_int
+            if h.vgen_host_abi_version() != 1:
+                raise RuntimeError(f"{path}: host ABI version {h.vgen_host_abi_version()} != 1 (rebuild: python -m vgen_amd.build)")
+            _HOST[0] = h
+    return _HOST[0]
+
+
+def _round_block_torch(W, U, i1, i2, dt, Q, E1):
+    """Columns [i1, i2): round column by column, feeding each column's error forward inside the block (fp32, one rounding per
+    operation).  csrc/host_round.cpp is this loop in C++, bit for bit."""
+    W1 = W[:, i1:i2].clone()
+    U1 = U[i1:i2, i1:i2]
+    # K x ~6 tiny tensor ops: on many threads each costs ~100 us of fork / join, on one ~15 us
+    threads = torch.get_num_threads()
+    torch.set_num_threads(1)
+    try:
+        for i in range(i2 - i1):
+            w = W1[:, i]
+            q = w.to(dt).float()
+            Q[:, i1 + i] = q
+            e = (w - q) / U1[i, i]
+            W1[:, i:] -= e[:, None] * U1[i, i:][None, :]
+            E1[:, i] = e
+    finally:
+        torch.set_num_threads(threads)
+
+
+def inverse_factor(H: torch.Tensor):
+    """fp64 [K, K] SPD -> the upper-triangular U with H^-1 = U^T U, or None if H is numerically singular.
+
+    One Cholesky and one triangular inverse: with J the index reversal, J H J = L L^T gives H = V V^T for the UPPER triangular
+    V = J L J, hence H^-1 = (V^-1)^T V^-1 and — the factor with positive diagonal being unique — U = V^-1.  (GPTQ's reference
+    recipe, cholesky -> cholesky_inverse -> cholesky(upper), is the same matrix for twice the flops.)"""
+    try:
+        L = torch.linalg.cholesky(H.flip(0, 1))
+    except RuntimeError:                            # torch.linalg.LinAlgError is a RuntimeError
+        return None
+    V = L.flip(0, 1)
+    try:
+        from scipy.linalg import lapack
+        Vi, info = lapack.dtrtri(V.numpy(), lower=0)            # K^3 / 3 flops (a triangular solve against I costs K^3)
+        U = torch.from_numpy(Vi) if info == 0 else None
+    except ImportError:
+        U = torch.linalg.solve_triangular(V, torch.eye(V.shape[0], dtype=V.dtype), upper=True)
+    if U is None or not bool(torch.isfinite(U).all()):
+        return None
+    return U.triu_()
+
+
+def gptq_round(W: torch.Tensor, H: torch.Tensor, dt, damp: float = 0.01, block: int = 128, use_host_lib: bool = True) -> torch.Tensor:
     """W fp32 [N, K], H fp32 [K, K] (= A^T A of the layer's input rows) -> Q [N, K] of dtype `dt` minimising
     ||A W^T - A Q^T|| greedily over roundings to `dt`, K-column by K-column with error feedback.  Host tensors."""
-    assert W.dim() == 2 and H.shape == (W.shape[1], W.shape[1])
-    W = W.detach().to(device="cpu", dtype=torch.float32).clone()
+    assert W.dim() == 2 and H.shape == (W.shape[1], W.shape[1]) and block <= 128
+    assert dt in (torch.float16, torch.bfloat16)
+    W = W.detach().to(device="cpu", dtype=torch.float32).contiguous().clone()
     H = H.detach().to(device="cpu", dtype=torch.float64).clone()
-    K = W.shape[1]
+    N, K = W.shape
     d = H.diagonal()
     dead = d <= 0                                   # an input column that is identically zero: its weight cannot matter
     H[dead, dead] = 1.0
@@ -51,35 +118,27 @@ def gptq_round(W: torch.Tensor, H: torch.Tensor, dt, damp: float = 0.01, block: 
     U = None
     for attempt in range(3):                        # a numerically singular H: more damping; at worst, to-nearest
         H.diagonal().add_(damp * (10.0 ** attempt) * mean_d)
-        try:
-            Hinv = torch.cholesky_inverse(torch.linalg.cholesky(H))
-            U = torch.linalg.cholesky(Hinv, upper=True).float()   # H^-1 = U^T U; row i of U = how column i's error spreads
+        U = inverse_factor(H)
+        if U is not None:
             break
-        except RuntimeError:                        # torch.linalg.LinAlgError is a RuntimeError
-            continue
-    if U is None or not bool(torch.isfinite(U).all()):
+    if U is None:
         return W.to(dt)
+    U = U.float().contiguous()                      # row i of U = how column i's error spreads over the later columns
     Q = torch.empty_like(W)
-    # the column loop is K x ~6 tiny tensor ops: on many threads each costs ~100 us of fork / join (measured on the GPU
-    # box: 15 s for the tiny UNet's 240 weights), on one ~15 us; the factorisations above keep the caller's thread count
-    threads = torch.get_num_threads()
-    torch.set_num_threads(1)
-    try:
-        for i1 in range(0, K, block):
-            i2 = min(i1 + block, K)
-            W1 = W[:, i1:i2].clone()
-            E1 = torch.zeros_like(W1)
-            U1 = U[i1:i2, i1:i2]
-            for i in range(i2 - i1):
-                w = W1[:, i]
-                q = w.to(dt).float()
-                Q[:, i1 + i] = q
-                e = (w - q) / U1[i, i]
-                W1[:, i:] -= e[:, None] * U1[i, i:][None, :]
-                E1[:, i] = e
+    hl = host_lib() if use_host_lib else None
+    nthreads = max(1, min(torch.get_num_threads(), 64))
+    for i1 in range(0, K, block):
+        i2 = min(i1 + block, K)
+        E1 = torch.zeros(N, i2 - i1)
+        if hl is not None:
+            rc = hl.vgen_host_gptq_block(W.data_ptr(), N, K, U.data_ptr(), K, i1, i2, 0 if dt == torch.float16 else 1,
+                                         Q.data_ptr(), K, E1.data_ptr(), i2 - i1, nthreads)
+            if rc != 0:
+                raise RuntimeError(f"vgen_host_gptq_block rejected its arguments (rc {rc})")
+        else:
+            _round_block_torch(W, U, i1, i2, dt, Q, E1)
+        if i2 < K:
             W[:, i2:] -= E1 @ U[i1:i2, i2:]
-    finally:
-        torch.set_num_threads(threads)
     return Q.to(dt)
 
 
