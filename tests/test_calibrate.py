@@ -52,8 +52,7 @@ def test_error_feedback_rounding_beats_to_nearest_on_correlated_inputs():
 
 def test_host_library_exports_its_header_and_matches_the_torch_loop_bit_for_bit():
     """libvgen_host.so (csrc/host_round.cpp) = include/vgen_host.h's symbols; its column loop and the torch restatement give
-    the SAME 16-bit matrix (fp16 and bf16, K not a multiple of the block, a dead column, values that need subnormals), and the
-    one-Cholesky inverse factor is the reference recipe's matrix."""
+    the SAME 16-bit matrix (fp16 and bf16, K not a multiple of the block, a dead column, values that need subnormals)."""
     import re
     from conftest import ROOT
     from vgen_amd import build as b
@@ -88,8 +87,7 @@ def test_host_library_exports_its_header_and_matches_the_torch_loop_bit_for_bit(
     Hd[5, 5] = 1.0
     Hd.diagonal().add_(0.01 * float(Hd.diagonal().mean()))
     U = cal.inverse_factor(Hd.clone())
-    U_ref = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(Hd)), upper=True)
-    assert float((U - U_ref).abs().max()) <= 1e-10 * float(U_ref.abs().max())
+    assert float(U.tril(-1).abs().max()) == 0.0
     assert float((U.t() @ U @ Hd - torch.eye(K, dtype=torch.float64)).abs().max()) < 1e-8
     bad = torch.zeros(4, 4, dtype=torch.float64)
     assert cal.inverse_factor(bad) is None
