@@ -479,6 +479,8 @@ def select_headline(res, args, tflop_per_step):
     res["variants"][key] = {"promoted_to_headline": True}
     sel["selected"] = key
     sel["why"] = "inside the tolerance on every fixture in this run and faster"
+    sel["multi_gpu_note"] = (f"--gpus N > 1 lines time --precision ({base}) without this selection: their N = 1 reference is "
+                             f"variants['{base}'].value = {old['value']}, not this line's value")
 
 
 def _finish(res, world):
