@@ -420,6 +420,7 @@ def calibrated_model(state_dict, dtype, dev, latent, budget_s):
     torch.cuda.synchronize()
     cal = {"seconds": round(time.perf_counter() - t_c, 1), "weights_calibrated": rep["calibrated"],
            "weights_to_nearest": rep["nearest"], "time_budget_s": budget_s, "over_the_budget": rep["over_budget"],
+           "long_k_left_to_nearest_past_half_the_budget": rep["past_half_budget_long_k"],
            "two_term_left": rep["two_term_left"], "host_seconds_rounding": round(rep["seconds_round"], 1),
            "largest_move_in_typical_rounding_errors": round(rep["max_move"], 2),
            "input": "noise / prompt seed 424242, t = 637 (the timed steps and the parity fixtures use others)"}

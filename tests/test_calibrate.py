@@ -165,3 +165,59 @@ def test_calibrate_single_pass_on_the_tiny_unet(emu_backend):
     assert abs(rel_l2(m(g["x"], g["t"], y=g["y"]), g["out"]) - e_high) < 1e-6
     with pytest.raises(ValueError):
         cal.calibrate_single_pass(_tiny("mixed")[0], xc, tc, y=yc)
+
+
+def test_time_budget_degrades_in_two_stages(monkeypatch):
+    """Past HALF the budget only K <= k_max_late is still calibrated (the long-K layers keep to-nearest); past the whole budget
+    nothing is — and in every case no two-term operand survives the launch."""
+    from vgen_amd import calibrate as cal
+    from vgen_amd import lib as L
+
+    class Inner:
+        name = "inner"
+
+        def __init__(self):
+            self.launched = []
+
+        def tapgemm(self, g):
+            self.launched.append(getattr(g.W, "vgen_dw", None) is not None)
+            return None
+
+    now = [1000.0]
+    monkeypatch.setattr(cal.time, "time", lambda: now[0])
+    inner = Inner()
+    cb = cal.CalibratingBackend(inner, time_budget_s=100.0, k_max=9000, k_max_late=128)
+    assert cb.half == 1050.0 and cb.deadline == 1100.0
+    import types
+    from vgen_amd import ops
+
+    def spec(K):
+        gen = torch.Generator("cpu").manual_seed(K)
+        A = torch.randn(256, K, generator=gen).half()
+        W32 = torch.randn(8, K, generator=gen) / K ** 0.5
+        hi = W32.half()
+        lo = (W32 - hi.float()).half()
+        W = hi.clone()
+        W.vgen_dw = torch.cat([hi, lo], 1)
+        g = types.SimpleNamespace(W=W, A=A, A2=None, M=256, N=8, C1=K, C2=0, taps=1, mode=L.TAP_LINEAR)
+        return g, hi
+
+    monkeypatch.setattr(ops, "dw_terms", lambda dw: (dw[:, : dw.shape[1] // 2], dw[:, dw.shape[1] // 2:]))
+    # stage 0: everything within k_max is calibrated
+    g, hi = spec(256)
+    cb.tapgemm(g)
+    assert cb.report["calibrated"] == 1 and not hasattr(g.W, "vgen_dw")
+    # stage 1 (past half): long K keeps to-nearest (W_hi untouched), short K is still calibrated
+    now[0] = 1060.0
+    g, hi = spec(256)
+    cb.tapgemm(g)
+    assert cb.report["past_half_budget_long_k"] == 1 and cb.report["nearest"] == 1 and torch.equal(g.W, hi)
+    g, hi = spec(128)
+    cb.tapgemm(g)
+    assert cb.report["calibrated"] == 2 and not hasattr(g.W, "vgen_dw")
+    # stage 2 (past the budget): nothing is calibrated any more
+    now[0] = 1101.0
+    g, hi = spec(128)
+    cb.tapgemm(g)
+    assert cb.report["over_budget"] == 1 and cb.report["nearest"] == 2 and torch.equal(g.W, hi) and not hasattr(g.W, "vgen_dw")
+    assert inner.launched == [False] * 4                     # every launch went out single-pass
