@@ -47,3 +47,7 @@ def test_sample_loop_matches_cpu_restatement(emu_backend):
     s._step_index = 3
     prev, den = s.step(v, s.timesteps[3], noise, return_dict=False)
     assert torch.equal(prev, den)
+    # reset(): the scheduler lets go of whatever session it cached (model reference, graphs), and keeps working
+    s.sessions._items["k"] = object()
+    s.reset()
+    assert not s.sessions._items and s._step_index is None

@@ -76,6 +76,12 @@ class LCMScheduler:
         # instead of re-capturing the model graph for a 4-step loop
         self.sessions = SessionCache(capacity=1)
 
+    def reset(self):
+        """Drop the cached sampling session (the model reference, its captured graphs and their memory pool) — e.g. between
+        two models driven by the same scheduler object (the cache otherwise lives as long as the scheduler)."""
+        self.sessions.clear()
+        self._step_index = None
+
     # -- schedule ------------------------------------------------------------------------------------------
     def set_timesteps(self, num_inference_steps, device=None, original_inference_steps=None, strength=1.0):
         orig = original_inference_steps or self.original_inference_steps
