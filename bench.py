@@ -53,6 +53,8 @@ samplers: `GaussianDiffusion.sample(solver='dpmpp_2m_sde')` CFG steps (value) an
 
 Objects on the JSON line — every number is measured in this run unless its key says `committed`:
   parity       — see above.
+  headline_selection — which of {--precision, calibrated} the line's value / parity / roofline belong to, both candidates'
+                 values, every check of the rule and why (select_headline; tests/test_bench_logic.py).
   roofline     — dominant kernel (tap-GEMM, MFMA-bound): algorithmic FLOP per launch (2 M N K of the product each
                  launch computes; a dual-W launch executes twice the MFMAs for it) / average launch duration, measured
                  with HIP events on the launch stream in an instrumented eager pass of the same step; peak = 2.5
