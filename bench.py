@@ -1044,7 +1044,7 @@ def main():
                 cal = None
                 calibrated = vpr == "calibrated"
                 if calibrated:
-                    vm, cal = calibrated_model(sd, vdt, dev, (C, F, H, W), budget_s=120.0)
+                    vm, cal = calibrated_model(sd, vdt, dev, (C, F, H, W), budget_s=150.0)
                 else:
                     vm = build_model("t2v", dev, vdt, vpr, state_dict=sd)
                 drop_masters(vm, dev)
@@ -1081,7 +1081,7 @@ def main():
                         if os.path.exists(GOLDEN_T2V_B):
                             gb_ = torch.load(GOLDEN_T2V_B, map_location="cpu", weights_only=False)
                             mb, calb = calibrated_model(seeded_state_dict(gb_["shapes"], seed=gb_["seed"], recipe=gb_["recipe"]),
-                                                        vdt, dev, (C, F, H, W), budget_s=90.0)
+                                                        vdt, dev, (C, F, H, W), budget_s=110.0)
                             fx[FIXTURE_NAMES[2]] = golden_parity(mb, gb_, dev)
                             ent["calibration_t2v_full_b"] = calb
                             del mb
