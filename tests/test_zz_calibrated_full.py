@@ -39,3 +39,26 @@ def test_calibrated_single_pass_full_size_meets_the_north_star_tolerance(hip_bac
         errs[name] = rel_l2(m(x.to(DEV), f["t"].to(DEV), y=y.to(DEV)), f["out"])
     _record("unet_t2v_full/fp16/calibrated", dict(errs, report={k: v for k, v in rep.items()}))
     assert max(errs.values()) <= NORTH_STAR, (errs, "emulator: see profiles/r05_emu_calibrated.txt")
+
+
+@pytest.mark.parametrize("name,emulated", [("t2v_b", 6.82e-4), ("videolcm", 8.14e-4), ("tft2v", 8.53e-4)])
+def test_calibrated_single_pass_on_the_other_full_width_fixtures(hip_backend, name, emulated):
+    """The recipe of tools/emu_calibrated.py on the GPU: the full-width model of the fixture packed two-term, calibrated on
+    noise / conditioning of seed 424242 at t = 637, then the fixture's own input against the reference's fp32 forward —
+    heavy-tailed t2v weights, UNetSD_VideoLCM at [1,4,16,32,56], UNetSD_TFT2V at [1,4,16,64,112].  `emulated` = what the ABI
+    emulator read for the same recipe (profiles/r05_emu_calibrated.txt); first GPU run = the driver's."""
+    import full_cases as fc
+    from vgen_amd.calibrate import calibrate_single_pass
+    g = fc.load(name)
+    m = fc.build(name, g, "high", DEV)
+    x, kw = fc.inputs(name, g)
+    gen = torch.Generator("cpu").manual_seed(424242)
+    xc = torch.randn(x.shape, generator=gen).to(DEV)
+    kwc = {k: (torch.randn(v.shape, generator=gen) if v.is_floating_point() else v).to(DEV) for k, v in kw.items()}
+    rep = calibrate_single_pass(m, xc, torch.full_like(g["t"], 637).to(DEV), **kwc)
+    assert rep["two_term_left"] == 0 and rep["calibrated"] > 300, rep
+    out = fc.forward(name, m, g, DEV)
+    err, nr = fc.error(out, g)
+    _record(f"unet_{name}_full/fp16/calibrated", dict(rel_l2=err, norm_ratio=nr, emulated=emulated, report=dict(rep)))
+    assert err <= NORTH_STAR, (err, emulated)
+    assert abs(nr - 1.0) < 5e-3
