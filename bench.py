@@ -1093,7 +1093,8 @@ def main():
                 try:                                            # the newest variant must not be able to cost the line
                     ent = run_variant()
                 except Exception as exc:                        # noqa: BLE001
-                    ent = {"failed": f"{type(exc).__name__}: {exc}"[:300]}
+                    import traceback
+                    ent = {"failed": f"{type(exc).__name__}: {exc}"[:300], "traceback_tail": traceback.format_exc()[-700:]}
             else:
                 ent = run_variant()
             res["variants"][v] = ent
