@@ -3,6 +3,8 @@
 (tests/test_gpu_model.py::test_calibrated_single_pass_tiny_on_device) and the emulator run of the same product code
 (profiles/r05_emu_calibrated.txt: 8.36e-4 / 8.16e-4) exist — so under `pytest -x` it must not be able to keep any other test
 from running.  The assertion is the north-star tolerance itself, unchanged."""
+import os
+
 import pytest
 import torch
 
@@ -41,7 +43,13 @@ def test_calibrated_single_pass_full_size_meets_the_north_star_tolerance(hip_bac
     assert max(errs.values()) <= NORTH_STAR, (errs, "emulator: see profiles/r05_emu_calibrated.txt")
 
 
-@pytest.mark.parametrize("name,emulated", [("t2v_b", 6.82e-4), ("videolcm", 8.14e-4), ("tft2v", 8.53e-4)])
+_SLOW = pytest.mark.skipif(os.environ.get("VGEN_GPU_SLOW") != "1",
+                           reason="1-2 minutes of host factorisations each: VGEN_GPU_SLOW=1 runs them (the default suite keeps "
+                                  "to the fixtures the bench line rests on, so that its run time stays where the round measured it)")
+
+
+@pytest.mark.parametrize("name,emulated", [("videolcm", 8.14e-4), pytest.param("t2v_b", 6.82e-4, marks=_SLOW),
+                                           pytest.param("tft2v", 8.53e-4, marks=_SLOW)])
 def test_calibrated_single_pass_on_the_other_full_width_fixtures(hip_backend, name, emulated):
     """The recipe of tools/emu_calibrated.py on the GPU: the full-width model of the fixture packed two-term, calibrated on
     noise / conditioning of seed 424242 at t = 637, then the fixture's own input against the reference's fp32 forward —
