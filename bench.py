@@ -19,28 +19,22 @@ each call's x_{t-1} fed to the next, t walking the 50-step DDIM schedule.  Under
 session (vgen_amd/session.py) replays one hipGraph per step; the untimed setup does two steps (eager
 warm-up + capture), like weight loading.
 
-HEADLINE = the fastest mode of THIS run that meets the north-star's tolerance IN this run (`headline_selection` on the line
-says which and why; `--headline fixed` pins it to --precision).  Two candidates:
-  * fp16, precision="mixed" (the product default, measured FIRST and completely): packed weights as W_hi + W_lo pairs (one
-    dual-W tap-GEMM launch per layer) in the blocks of the FULL-RESOLUTION level (encoder and decoder level 0, + the context
-    K/V projection and the head conv; the FeedForward pair and the cross-attention query stay single-pass:
-    UNetSD_T2VBase.MIXED_SINGLE_KINDS), where 82 % of the output's sensitivity to weight rounding sits: UNet
-    output <= 1e-3 rel-L2 of the reference's fp32 forward — measured on seeded synthetic weights (no checkpoints offline):
-    three full-size t2v fixtures (two weight recipes, three timesteps) and the full-width I2VGen / VideoLCM / TFT2V / SR600
-    fixtures; on the 3-level dim-64 test model the same rule lands at 1.1e-3.
-  * fp16, "calibrated" (vgen_amd/calibrate.py, r05): EVERY weight one 16-bit matrix — single-pass launches only, the kernels
-    of precision="fast" — whose rounding was chosen at pack time by error feedback from one calibration forward (other noise,
-    prompt and timestep than anything timed or checked).  Emulated at 8.36e-4 / 8.16e-4 / 6.82e-4 on the three fixtures; the
-    round's GPU budget ended before it could be timed at full size, so it is promoted ONLY by this run's own numbers: all
-    three fixtures <= 1e-3, finite, the same K / W, no two-term weight left, and faster.  Otherwise — or if anything in it
-    raises — the line is the mixed mode's, untouched; the replaced mode always stays on the line under `variants`.
+HEADLINE MODE (r06): fp16, precision "calibrated" (vgen_amd/calibrate.py) on EVERY leg of this script (the timed steps, e2e,
+scaling_model, --partition, --gpus N > 1, the other --config shapes): every packed weight is ONE 16-bit matrix — single-pass
+launches only, the kernels of precision="fast" — whose rounding was chosen at pack time by error feedback from one forward on
+a seeded calibration batch (calibrate.calibration_batch: 8 noise / prompt draws at 8 timesteps spread over the schedule, none
+of them timed or parity-checked).  Which launches are calibrated is a rule of their sizes (K <= 9000 and rows >= 2 K); there is
+no wall clock in the pass, so the same weights always pack the same bits (`calibration.packed_digest` on the line).  Pack-time
+work (like weight loading): `calibration.seconds` reports it, the timed region starts after it.  With N > 1 rank 0 calibrates
+and saves (calibrate.save_calibrated), the other ranks build `precision="calibrated", calibration=<file>` — the persistent
+route a deployment uses.
 `parity.unet_rel_l2` is COMPUTED IN THIS RUN (max over the three t2v fixtures): the timed model evaluates the golden
-fixtures' inputs and is compared with the reference's recorded fp32 outputs; a value outside the tolerance sets
-`parity_exceeds_tolerance` on the line and warns on stderr.  `variants` carries timed steps + parity (this run, same process)
-for fp16/high (two-term weights everywhere: the largest margin), fp16/fast (one 16-bit operand pair per GEMM, weights to
-nearest: the reference's own autocast arithmetic) and bf16/fast (BASELINE.json's literal "bf16") — the last two faster and
-outside 1e-3.  `roofline` / `hbm_kernels` / `parity` belong to the headline mode; `e2e`, `scaling_model` and `vae` are taken on
-the --precision model and carry their own precision key.
+fixtures' inputs and is compared with the reference's recorded fp32 outputs (the third fixture has its own weights: its model
+is calibrated the same way); a value outside the tolerance sets `parity_exceeds_tolerance` on the line and warns on stderr.
+`variants` carries timed steps + parity (this run, same process) for fp16/mixed (two-term weights at the full-resolution
+level: the r03-r05 default, 1.13x the launches' MFMA work), fp16/high (two-term weights everywhere: the largest margin),
+fp16/fast (weights to nearest: the reference's own autocast arithmetic) and bf16/fast (BASELINE.json's literal "bf16") — the
+last two outside 1e-3.
 
 N > 1 (weak scaling): P = N prompts in flight -> 2N units spread over the ranks, ONE all-gather of the unit
 outputs per step (RCCL), every rank applies the cheap update for all prompts.  value = prompts * steps /
@@ -53,8 +47,8 @@ samplers: `GaussianDiffusion.sample(solver='dpmpp_2m_sde')` CFG steps (value) an
 
 Objects on the JSON line — every number is measured in this run unless its key says `committed`:
   parity       — see above.
-  headline_selection — which of {--precision, calibrated} the line's value / parity / roofline belong to, both candidates'
-                 values, every check of the rule and why (select_headline; tests/test_bench_logic.py).
+  calibration  — the report of the pack-time calibration pass of the timed model (counts per decision, the rule, host
+                 seconds, a digest of the per-launch decisions and of the packed bits).
   roofline     — dominant kernel (tap-GEMM, MFMA-bound): algorithmic FLOP per launch (2 M N K of the product each
                  launch computes; a dual-W launch executes twice the MFMAs for it) / average launch duration, measured
                  with HIP events on the launch stream in an instrumented eager pass of the same step; peak = 2.5
@@ -170,13 +164,40 @@ def model_class(name):
     return getattr(importlib.import_module("vgen_amd." + modname), clsname)
 
 
-def build_model(name, dev, dtype, precision="high", state_dict=None):
+def calibrate_model(name, model, dev):
+    """precision="high" -> "calibrated" in place (vgen_amd/calibrate.py) on the family's seeded calibration batch: noise /
+    prompts / timesteps of calibrate.calibration_batch + this family's conditioning tensors with the same batch size.  Returns
+    the brief report (+ wall seconds)."""
+    from vgen_amd import calibrate as cal
+    t0 = time.perf_counter()
+    x, t, y = cal.calibration_batch(CONFIGS[name]["latent"], device=dev)
+    n = x.shape[0]
+    kw = conditioning(name, model, n, dev, torch.Generator(device=dev).manual_seed(424243))[0]
+    kw["y"] = y
+    rep = cal.calibrate_single_pass(model, x, t, **kw)
+    if torch.device(dev).type == "cuda":
+        torch.cuda.synchronize()
+    out = cal.brief_report(rep)
+    out.update(seconds=round(time.perf_counter() - t0, 1), timesteps=t.tolist(),
+               input="calibrate.calibration_batch seed 424242 (+ the family's conditioning, seed 424243): none of it timed or "
+                     "parity-checked")
+    return out
+
+
+def build_model(name, dev, dtype, precision="high", state_dict=None, calibration=None):
     """The model of config `name` on `dev`, packed.  state_dict: fp32 CPU parameters to load (the golden fixture's
-    weights for t2v); None = device-side seeded random init."""
+    weights for t2v); None = device-side seeded random init.  precision="calibrated": packed two-term and calibrated here
+    (calibrate_model; the report is left on model.bench_calibration) — or, with calibration=<file>, loaded from a file another
+    rank's pass saved."""
     import types
     c = CONFIGS[name]
     cls = model_class(name)
     kw = dict(c["cfg"])
+    want_cal = precision == "calibrated"
+    if want_cal and calibration is None:
+        precision = "high"
+    elif want_cal:
+        kw["calibration"] = calibration
     if "comps" in c:
         kw["config"] = types.SimpleNamespace(video_compositions=c["comps"], resolution=[c["latent"][3] * 8, c["latent"][2] * 8])
     if state_dict is not None:
@@ -191,6 +212,11 @@ def build_model(name, dev, dtype, precision="high", state_dict=None):
         model.eval()
         randomize_(model, 0)
     model.pack()
+    if want_cal and calibration is None:
+        model.bench_calibration = calibrate_model(name, model, dev)
+    elif want_cal:
+        model.bench_calibration = {"loaded_from": calibration, **{k: v for k, v in (model._calibration_report or {}).items()
+                                                                  if k != "layers"}}
     return model
 
 
@@ -285,8 +311,7 @@ class StepTimer:
 def roofline_pass(args, model, timer, xt0, kw, G, guide, precision):
     """Roofline of the dominant kernel class for `model`: ONE instrumented eager pass of the same step (every launch bracketed
     by HIP events on the launch stream), the GroupNorm / LayerNorm launches of that pass against the HBM peak.  Returns
-    {"roofline": ..., "hbm_kernels": ...} measured on the model that is passed in (the headline mode, and — for the headline
-    selection — the calibrated single-pass model)."""
+    {"roofline": ..., "hbm_kernels": ...} measured on the model that is passed in."""
     from vgen_amd import ops
     from vgen_amd.diffusion import DiffusionDDIM
     res = {}
@@ -363,7 +388,7 @@ def roofline_pass(args, model, timer, xt0, kw, G, guide, precision):
                                    "beside 1.28 k cycles of MFMAs; stamped K-step 2.0 k cycles (DESIGN 3.1)"}}
     # HBM-side bytes per launch cannot be read from inside the process: they come from committed rocprofv3 PMC
     # passes of this command (tools/collect_evidence.sh -> profiles/) and are labelled as such
-    for tname in ("r05n_tapgemm_traffic.json", "r05_tapgemm_traffic.json", "r04_tapgemm_traffic.json", "r03_tapgemm_traffic.json", "r02_tapgemm_traffic.json"):
+    for tname in ("r06_tapgemm_traffic.json", "r05n_tapgemm_traffic.json", "r05_tapgemm_traffic.json", "r04_tapgemm_traffic.json", "r03_tapgemm_traffic.json", "r02_tapgemm_traffic.json"):
         tpath = os.path.join(ROOT, "profiles", tname)
         if os.path.exists(tpath):
             tj = json.load(open(tpath))
@@ -405,85 +430,6 @@ def parity_block(fx, dtype, precision):
             "fixtures": {k: round(v, 7) for k, v in fx.items()},
             "golden": "tests/golden/unet_t2v_full{,_c,_b}.pt: the reference's fp32 UNetSD_T2VBase forward on the "
                       "same seeded weights and inputs (oracle/make_golden.py); unet_rel_l2 = max over the fixtures"}
-
-
-def calibrated_model(state_dict, dtype, dev, latent, budget_s):
-    """r05 (vgen_amd/calibrate.py): the t2v UNet with EVERY weight single-pass, its 16-bit rounding chosen by error feedback
-    from ONE calibration forward — on other noise, prompt and timestep (seed 424242, t = 637) than anything timed or
-    parity-checked.  Pack-time work (like weight loading), reported next to the mode.  Returns (model, report)."""
-    from vgen_amd.calibrate import calibrate_single_pass
-    C, F, H, W = latent
-    vm = build_model("t2v", dev, dtype, "high", state_dict=state_dict)
-    cg = torch.Generator(device=dev).manual_seed(424242)
-    t_c = time.perf_counter()
-    rep = calibrate_single_pass(vm, torch.randn(1, C, F, H, W, generator=cg, device=dev),
-                                torch.full((1,), 637, dtype=torch.long, device=dev),
-                                y=torch.randn(1, 77, 1024, generator=cg, device=dev), time_budget_s=budget_s)
-    torch.cuda.synchronize()
-    cal = {"seconds": round(time.perf_counter() - t_c, 1), "weights_calibrated": rep["calibrated"],
-           "weights_to_nearest": rep["nearest"], "time_budget_s": budget_s, "over_the_budget": rep["over_budget"],
-           "long_k_left_to_nearest_past_half_the_budget": rep["past_half_budget_long_k"],
-           "two_term_left": rep["two_term_left"], "host_seconds_rounding": round(rep["seconds_round"], 1),
-           "largest_move_in_typical_rounding_errors": round(rep["max_move"], 2),
-           "input": "noise / prompt seed 424242, t = 637 (the timed steps and the parity fixtures use others)"}
-    return vm, cal
-
-
-def select_headline(res, args, tflop_per_step):
-    """Make the calibrated single-pass model the line's headline iff this run measured it inside the tolerance on every
-    fixture, finite, under the same K / W, and faster than the --precision mode (or that mode is outside the tolerance).  The
-    replaced mode's numbers move to variants[dtype/precision]; objects that were taken on the --precision model only (e2e,
-    scaling_model, vae) carry their own `precision` key."""
-    key = f"{args.dtype}/calibrated"
-    base = f"{args.dtype}/{args.precision}"
-    cand = res["variants"].get(key)
-    sel = {"rule": "fastest mode of THIS run whose in-run parity is <= 1e-3 on all three reference fixtures, among "
-                   f"{{{base}, {key}}}; {base} is measured first and completely", "selected": base,
-           "candidates": {base: {"value": res["value"], "unet_rel_l2": res.get("parity", {}).get("unet_rel_l2")}}}
-    res["headline_selection"] = sel
-    if cand is None or args.headline != "auto":
-        sel["why"] = "calibrated mode not run" if cand is None else "--headline fixed"
-        return
-    if "failed" in cand:
-        sel["candidates"][key] = {"failed": cand["failed"]}
-        sel["why"] = "the calibrated mode failed"
-        return
-    sel["candidates"][key] = {"value": cand["value"], "unet_rel_l2": cand.get("unet_rel_l2")}
-    par = cand.get("parity")
-    checks = {"parity_measured_on_all_fixtures": bool(par and len(par["fixtures"]) == len(FIXTURE_NAMES)),
-              "within_tolerance": bool(par and par["within_tolerance"]), "finite": bool(cand.get("finite")),
-              "same_steps_and_warmup": cand.get("steps") == args.steps and cand.get("warmup") == args.warmup,
-              "no_two_term_weight_left": cand["calibration"]["two_term_left"] == 0,
-              "faster_or_base_outside_tolerance": cand["value"] > res["value"] or
-              not res.get("parity", {}).get("within_tolerance", False)}
-    sel["checks"] = checks
-    if not all(checks.values()) or "parity" not in res:
-        sel["why"] = "a check failed: " + ", ".join(k for k, ok in checks.items() if not ok)
-        return
-    moved = ("value", "ms_per_step", "parity", "roofline", "hbm_kernels", "finite", "latent_absmax_after_timed_steps",
-             "model_tflops_per_s", "frac_of_mfma_peak")
-    old = {k: res[k] for k in moved if k in res}
-    old.update(unit="steps/s", steps=args.steps, warmup=args.warmup, dtype=args.dtype, precision=args.precision,
-               two_term_weights=res["config"]["two_term_weights"], unet_rel_l2=res["parity"]["unet_rel_l2"],
-               within_tolerance=res["parity"]["within_tolerance"])
-    for k in ("value", "ms_per_step", "parity", "roofline", "hbm_kernels", "finite", "latent_absmax_after_timed_steps"):
-        if k in cand:
-            res[k] = cand[k]
-        else:
-            res.pop(k, None)
-    res["model_tflops_per_s"] = round(tflop_per_step * res["value"], 2)
-    res["frac_of_mfma_peak"] = round(tflop_per_step * res["value"] / PEAK_TFLOPS, 4)
-    res["config"]["precision"] = "calibrated"
-    res["config"]["two_term_weights"] = ("none: every packed weight is ONE 16-bit matrix whose rounding was calibrated at pack "
-                                         "time (vgen_amd/calibrate.py) — single-pass launches only")
-    res["config"]["calibration"] = {k: cand[k] for k in ("calibration", "calibration_t2v_full_b", "note") if k in cand}
-    res.pop("parity_exceeds_tolerance", None)
-    res["variants"][base] = old
-    res["variants"][key] = {"promoted_to_headline": True}
-    sel["selected"] = key
-    sel["why"] = "inside the tolerance on every fixture in this run and faster"
-    sel["multi_gpu_note"] = (f"--gpus N > 1 lines time --precision ({base}) without this selection: their N = 1 reference is "
-                             f"variants['{base}'].value = {old['value']}, not this line's value")
 
 
 def _finish(res, world):
@@ -664,17 +610,14 @@ def main():
                     help="t2v (default, BASELINE config 2: the driver's line); videolcm = whole videos through the 4-step LCM loop "
                          "+ decode (config 4); tft2v_sr600 = the two-stage pipeline for one video (config 5; --steps < 10 runs a "
                          "2-step smoke of every stage); the others time one denoise step of that shape")
-    ap.add_argument("--precision", default="mixed",
-                    help="mixed (default): packed weights as W_hi + W_lo pairs (dual-W tap-GEMM launches) in the full-resolution "
-                         "level (encoder + decoder level 0, K/V projection, head) — UNet output within 1e-3 rel-L2 of the "
-                         "reference's fp32 forward on the full-width fixtures; high: two-term "
-                         "weights everywhere; fast: one 16-bit operand pair per GEMM (the reference's autocast arithmetic; "
-                         "1.33e-3); mixed:e0d01t1-style strings select levels (vgen_amd/unet.py)")
-    ap.add_argument("--variants", default="fp16/high,fp16/fast,bf16/fast,fp16/calibrated",
+    ap.add_argument("--precision", default="calibrated",
+                    help="calibrated (default, r06): every weight ONE 16-bit matrix whose rounding was calibrated at pack time "
+                         "(vgen_amd/calibrate.py; single-pass launches only); mixed: packed weights as W_hi + W_lo pairs (dual-W "
+                         "tap-GEMM launches) in the full-resolution level (encoder + decoder level 0, K/V projection, head); high: "
+                         "two-term weights everywhere; fast: weights to nearest (the reference's autocast arithmetic; 1.33e-3); "
+                         "mixed:e0d01t1-style strings select levels (vgen_amd/unet.py)")
+    ap.add_argument("--variants", default="fp16/mixed,fp16/high,fp16/fast,bf16/fast",
                     help="other dtype/precision modes timed + parity-checked after the headline mode (t2v, N = 1); '' = none")
-    ap.add_argument("--headline", default="auto", choices=["auto", "fixed"],
-                    help="auto (default): the line's value is the fastest mode of this run whose in-run parity is <= 1e-3 on all "
-                         "three reference fixtures, among {--precision, calibrated} (select_headline); fixed: always --precision")
     ap.add_argument("--stage1", default="text_image", choices=["text_image", "vcomposer"],
                     help="--config tft2v_sr600: composition list of the first stage (vcomposer = the reference yaml's eight "
                          "entries with six pixel-resolution condition maps)")
@@ -755,7 +698,32 @@ def main():
         # the golden fixture's weights: shapes + seed -> the tensors the reference's fp32 forward was recorded on
         gold = torch.load(GOLDEN_T2V, map_location="cpu", weights_only=False)
         sd = seeded_state_dict(gold["shapes"], seed=gold["seed"])
-    model = build_model(args.config, dev, args.dtype, args.precision, state_dict=sd)
+    cal_file = None
+    if world > 1 and args.precision == "calibrated":
+        # the persistent route (calibrate.save_calibrated / precision="calibrated", calibration=<file>): ONE rank pays the
+        # pack-time pass, the others load its result — the same bits either way (the pass is deterministic)
+        import tempfile
+        cal_file = os.path.join(tempfile.gettempdir(), f"vgen_bench_{args.config}_{args.dtype}_{os.environ.get('MASTER_PORT', '0')}.cal")
+        ok = torch.zeros(1, device=dev)
+        if rank == 0:
+            try:
+                model = build_model(args.config, dev, args.dtype, "calibrated", state_dict=sd)
+                from vgen_amd.calibrate import save_calibrated
+                save_calibrated(model, cal_file)
+                ok += 1
+            except OSError as exc:                       # no room for the file: every rank calibrates for itself
+                print(f"bench.py: could not save {cal_file} ({exc}); every rank calibrates its own copy", file=sys.stderr)
+                model = None
+        dist.all_reduce(ok)                              # also the barrier the other ranks wait at
+        if float(ok.item()) < 1:
+            cal_file = None
+        if rank != 0 or model is None:
+            model = build_model(args.config, dev, args.dtype, "calibrated", state_dict=sd, calibration=cal_file)
+        dist.barrier()
+        if rank == 0 and cal_file and os.path.exists(cal_file):
+            os.remove(cal_file)
+    else:
+        model = build_model(args.config, dev, args.dtype, args.precision, state_dict=sd)
     if args.config == "t2v":
         drop_masters(model, dev)
     if args.config == "videolcm":
@@ -851,7 +819,9 @@ def main():
                                                                   getattr(model, "MIXED_EXTRA_KINDS", {}).items()},
                                          "plus": "context K/V projection, head conv"}
                                         if getattr(model, "precision", "") == "mixed" else
-                                        ("all" if getattr(model, "precision", "") == "high" else "none (the 4 -> 320 stem only)")),
+                                        {"high": "all", "calibrated": "none: every packed weight is ONE 16-bit matrix whose rounding "
+                                         "was calibrated at pack time (vgen_amd/calibrate.py) — single-pass launches only"}
+                                        .get(getattr(model, "precision", ""), "none (the 4 -> 320 stem only)")),
                    "two_term_activations": bool(getattr(model, "_asplit", False)),
                    "weights": "seeded synthetic (vgen_amd/synth.py)" + (": the golden fixture's" if gold is not None else "")},
         "finite": finite, "latent_absmax_after_timed_steps": xt_absmax,
@@ -860,6 +830,11 @@ def main():
     }
     if inversion is not None:
         res["inversion"] = inversion
+    if getattr(model, "bench_calibration", None) is not None:
+        res["calibration"] = dict(model.bench_calibration)
+        if rank == 0 and world == 1 and args.config == "t2v":
+            from vgen_amd.calibrate import packed_digest
+            res["calibration"]["packed_digest"] = packed_digest(model)[:16]
 
     # ---- parity of the model that was just timed, computed here --------------------------------------------
     if rank == 0 and gold is not None and not args.no_parity:
@@ -873,6 +848,8 @@ def main():
             mb = build_model("t2v", dev, args.dtype, args.precision,
                              state_dict=seeded_state_dict(gb_["shapes"], seed=gb_["seed"], recipe=gb_["recipe"]))
             fx[FIXTURE_NAMES[2]] = golden_parity(mb, gb_, dev)
+            if getattr(mb, "bench_calibration", None) is not None:
+                res["calibration_t2v_full_b"] = mb.bench_calibration
             del mb
             gc.collect()
             torch.cuda.empty_cache()
@@ -1039,84 +1016,32 @@ def main():
             vdt, vpr = v.split("/")
             if (vdt, vpr) == (args.dtype, args.precision):
                 continue
-
-            def run_variant():
-                cal = None
-                calibrated = vpr == "calibrated"
-                if calibrated:
-                    vm, cal = calibrated_model(sd, vdt, dev, (C, F, H, W), budget_s=150.0)
-                else:
-                    vm = build_model("t2v", dev, vdt, vpr, state_dict=sd)
+            try:                                                # a variant must not be able to cost the line
+                vm = build_model("t2v", dev, vdt, vpr, state_dict=sd)
                 drop_masters(vm, dev)
                 vd = DiffusionDDIM(**DDIM)
                 vd.rng_parity = False
                 vt = StepTimer(vd, vm, xt0, mkw, guide, dev, P)
-                # the calibrated model is a candidate for the headline: EXACTLY --steps timed steps after --warmup, like it
-                k, w = (args.steps, args.warmup) if calibrated else (min(args.steps, 10), min(args.warmup, 2))
+                k, w = min(args.steps, 10), min(args.warmup, 2)
                 vdt_s, vx = vt.run(k, w)
                 ent = {"value": round(k / vdt_s, 4), "unit": "steps/s", "ms_per_step": round(1e3 * vdt_s / k, 3), "steps": k,
                        "warmup": w, "dtype": vdt, "precision": vpr, "finite": bool(torch.isfinite(vx).all()),
                        "latent_absmax_after_timed_steps": float(vx.float().abs().nan_to_num(nan=float("inf")).max())}
-                if not args.no_parity and not calibrated:
+                if not args.no_parity:
                     e = golden_parity(vm, gold, dev)
                     ent.update(unet_rel_l2=e, within_tolerance=bool(e <= TOLERANCE))
-                if cal is not None:
-                    ent["calibration"] = cal
-                    ent["note"] = ("precision='high' + vgen_amd.calibrate.calibrate_single_pass: one 16-bit matrix per layer, "
-                                   "single-pass launches; the r05 GPU budget ended before this mode could be timed at full size: "
-                                   "its first GPU measurement is the run that printed this line (emulator prediction: "
-                                   "profiles/r05_emu_calibrated.txt, 8.36e-4 / 8.16e-4 / 6.82e-4)")
-                    if not args.no_roofline:
-                        ent.update(roofline_pass(args, vm, vt, xt0, kw, G, guide, "calibrated"))
-                    if not args.no_parity:
-                        # the headline's three fixtures; the third has its own weights, so its model is calibrated too
-                        fx = {FIXTURE_NAMES[0]: golden_parity(vm, gold, dev)}
-                        if os.path.exists(GOLDEN_T2V_C):
-                            fx[FIXTURE_NAMES[1]] = golden_parity(
-                                vm, torch.load(GOLDEN_T2V_C, map_location="cpu", weights_only=False), dev)
-                        del vt, vd
-                        vm = None
-                        gc.collect()
-                        torch.cuda.empty_cache()
-                        if os.path.exists(GOLDEN_T2V_B):
-                            gb_ = torch.load(GOLDEN_T2V_B, map_location="cpu", weights_only=False)
-                            mb, calb = calibrated_model(seeded_state_dict(gb_["shapes"], seed=gb_["seed"], recipe=gb_["recipe"]),
-                                                        vdt, dev, (C, F, H, W), budget_s=110.0)
-                            fx[FIXTURE_NAMES[2]] = golden_parity(mb, gb_, dev)
-                            ent["calibration_t2v_full_b"] = calb
-                            del mb
-                        ent["parity"] = parity_block(fx, vdt, vpr)
-                        ent.update(unet_rel_l2=ent["parity"]["unet_rel_l2"], within_tolerance=ent["parity"]["within_tolerance"])
-                return ent
-
-            if vpr == "calibrated":
-                try:                                            # the newest variant must not be able to cost the line
-                    ent = run_variant()
-                except Exception as exc:                        # noqa: BLE001
-                    import traceback
-                    ent = {"failed": f"{type(exc).__name__}: {exc}"[:300], "traceback_tail": traceback.format_exc()[-700:]}
-            else:
-                ent = run_variant()
+                if getattr(vm, "bench_calibration", None) is not None:
+                    ent["calibration"] = vm.bench_calibration
+                del vm, vd, vt, vx
+            except Exception as exc:                            # noqa: BLE001
+                import traceback
+                ent = {"failed": f"{type(exc).__name__}: {exc}"[:300], "traceback_tail": traceback.format_exc()[-700:]}
             res["variants"][v] = ent
             gc.collect()
             try:
                 torch.cuda.empty_cache()
-            except Exception:                                   # noqa: BLE001 — a device error inside the newest variant: the
+            except Exception:                                   # noqa: BLE001 — a device error inside a variant: the
                 pass                                            # measurements taken before it still print
-
-    # ---- headline selection ------------------------------------------------------------------------------------------------
-    # The north-star is a rate AT a tolerance, so the line's `value` is the fastest mode of this run whose parity — computed in
-    # this run, on the same three reference fixtures — is inside 1e-3, out of {--precision (mixed), calibrated}.  The known-good
-    # mode is always measured FIRST and completely; the calibrated model can only replace it with numbers this process took
-    # under the same K / W, and the replaced mode stays on the line under `variants`.
-    if rank == 0 and "variants" in res:
-        try:
-            import copy
-            cand_line = copy.deepcopy(res)                      # all-or-nothing: a failure half way leaves `res` as measured
-            select_headline(cand_line, args, G * cfg["tflop"])
-            res = cand_line
-        except Exception as exc:                                # noqa: BLE001 — selection must not be able to cost the line
-            res["headline_selection"] = {"selected": f"{args.dtype}/{args.precision}", "error": f"{type(exc).__name__}: {exc}"[:200]}
 
     # ---- CPU baseline on the host cores, bounded sample ----------------------------------------------------------
     # Sample = ONE full forward of the full-size UNetSD_T2VBase (1411 M params) on the whole 16-frame latent

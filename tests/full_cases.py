@@ -70,6 +70,40 @@ def inputs(name, g):
     return x, kw
 
 
+def calibration_inputs(name, g, dev="cpu", n=None, seed=424242):
+    """(x, t, kwargs): the calibration batch of vgen_amd.calibrate.calibration_batch for this fixture's model family — other
+    noise, prompts and timesteps than the fixture's, plus the family's own conditioning drawn from the same seed with the
+    same leading batch size."""
+    from vgen_amd.calibrate import calibration_batch
+    shape = SHAPE.get(name, (1, 4, 16, 32, 56))[1:]
+    x, t, y = calibration_batch(shape, n=n, seed=seed)
+    n = x.shape[0]
+    assert int(g["t"].reshape(-1)[0]) not in t.tolist()
+    gen = torch.Generator("cpu").manual_seed(seed + 1)
+    kw = dict(y=y)
+    if name in ("tft2v", "i2vgen", "i2vgen_b", "vcomposer"):
+        kw["image"] = torch.randn(n, 1, 1024, generator=gen)
+    if name in ("i2vgen", "i2vgen_b"):
+        kw["local_image"] = torch.randn(n, 4, 88, 160, generator=gen)
+        kw["fps"] = g["fps"].reshape(-1)[:1].repeat(n)
+    if name == "vcomposer":
+        F_, (W_, H_) = shape[1], g["resolution"]
+        mk = lambda c: torch.randn(n, c, F_, H_, W_, generator=gen).half().float()
+        kw.update(depth=mk(1), sketch=mk(1), single_sketch=mk(1), motion=mk(2), local_image=mk(3), masked=mk(4))
+    if g["t"].is_floating_point():
+        t = t.to(g["t"].dtype)
+    return x.to(dev), t.to(dev), {k: v.to(dev) for k, v in kw.items()}
+
+
+def calibrate(name, m, g, dev="cpu", **opts):
+    """calibrate_single_pass on the family's calibration batch; returns the report."""
+    from vgen_amd.calibrate import calibrate_single_pass
+    x, t, kw = calibration_inputs(name, g, dev)
+    if name == "sr600":
+        return calibrate_single_pass(m, x, t, y=kw["y"], **opts)
+    return calibrate_single_pass(m, x, t, **kw, **opts)
+
+
 def forward(name, m, g, dev="cpu"):
     x, kw = inputs(name, g)
     kw = {k: v.to(dev) for k, v in kw.items()}

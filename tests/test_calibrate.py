@@ -128,10 +128,9 @@ def test_calibrate_single_pass_on_the_tiny_unet(emu_backend):
     from vgen_amd import ops
     m, g, sd = _tiny("high")
     e_high = rel_l2(m(g["x"], g["t"], y=g["y"]), g["out"])
-    gen = torch.Generator("cpu").manual_seed(99)
-    xc, yc = torch.randn(g["x"].shape, generator=gen), torch.randn(g["y"].shape, generator=gen)
-    tc = torch.full_like(g["t"], 333)
-    assert not bool((g["t"] == 333).any())
+    # a calibration BATCH (r06): 4 noise / prompt draws at 4 timesteps — none of them the fixture's
+    xc, tc, yc = cal.calibration_batch(tuple(g["x"].shape[1:]), n=4, seed=99, context=tuple(g["y"].shape[1:]))
+    assert not bool((tc == int(g["t"][0])).any())
     # baseline in the same structure: every weight to-nearest (k_max = 0 -> no launch is calibrated)
     mn, _, _ = _tiny("high")
     rep_n = cal.calibrate_single_pass(mn, xc, tc, y=yc, k_max=0)
@@ -167,57 +166,138 @@ def test_calibrate_single_pass_on_the_tiny_unet(emu_backend):
         cal.calibrate_single_pass(_tiny("mixed")[0], xc, tc, y=yc)
 
 
-def test_time_budget_degrades_in_two_stages(monkeypatch):
-    """Past HALF the budget only K <= k_max_late is still calibrated (the long-K layers keep to-nearest); past the whole budget
-    nothing is — and in every case no two-term operand survives the launch."""
-    from vgen_amd import calibrate as cal
+def _fake_launch(K, M=256, seed=None):
+    """A two-term linear launch spec the CalibratingBackend can round (no model, no backend underneath)."""
+    import types
     from vgen_amd import lib as L
+    from vgen_amd import ops
+    gen = torch.Generator("cpu").manual_seed(K if seed is None else seed)
+    A = torch.randn(M, K, generator=gen).half()
+    W32 = torch.randn(8, K, generator=gen) / K ** 0.5
+    W = ops.split_weight(W32, torch.float16)
+    return types.SimpleNamespace(W=W, A=A, A2=None, M=M, N=8, C1=K, C2=0, taps=1, mode=L.TAP_LINEAR), W32.half()
 
-    class Inner:
-        name = "inner"
 
-        def __init__(self):
-            self.launched = []
+class _Inner:
+    name = "inner"
 
-        def tapgemm(self, g):
-            self.launched.append(getattr(g.W, "vgen_dw", None) is not None)
-            return None
+    def __init__(self):
+        self.launched = []
 
+    def tapgemm(self, g):
+        self.launched.append(getattr(g.W, "vgen_dw", None) is not None)
+        return None
+
+
+def test_which_launches_are_calibrated_is_a_rule_of_their_sizes_not_of_the_clock(monkeypatch):
+    """r06 (VERDICT r05 next #1a / ADVICE r05): K <= k_max and rows >= min_rows_per_k * K -> error feedback, else to-nearest;
+    the wall clock can only ABORT the pass.  Two passes over the same launches give the same bits whatever the clock does."""
+    from vgen_amd import calibrate as cal
     now = [1000.0]
     monkeypatch.setattr(cal.time, "time", lambda: now[0])
-    inner = Inner()
-    cb = cal.CalibratingBackend(inner, time_budget_s=100.0, k_max=9000, k_max_late=128)
-    assert cb.half == 1050.0 and cb.deadline == 1100.0
-    import types
-    from vgen_amd import ops
 
-    def spec(K):
-        gen = torch.Generator("cpu").manual_seed(K)
-        A = torch.randn(256, K, generator=gen).half()
-        W32 = torch.randn(8, K, generator=gen) / K ** 0.5
-        hi = W32.half()
-        lo = (W32 - hi.float()).half()
-        W = hi.clone()
-        W.vgen_dw = torch.cat([hi, lo], 1)
-        g = types.SimpleNamespace(W=W, A=A, A2=None, M=256, N=8, C1=K, C2=0, taps=1, mode=L.TAP_LINEAR)
-        return g, hi
+    def one_pass(advance):
+        inner = _Inner()
+        cb = cal.CalibratingBackend(inner, k_max=300, min_rows_per_k=2.0)
+        out = []
+        for K, M in ((128, 256), (128, 255), (256, 512), (320, 4096), (64, 128)):
+            g, near = _fake_launch(K, M)
+            cb.tapgemm(g)
+            now[0] += advance                                 # a slow host and a fast host ...
+            out.append((g.W.clone(), near))
+            assert not hasattr(g.W, "vgen_dw")
+        assert inner.launched == [False] * 5                  # every launch went out single-pass
+        return cb.report, out
 
-    monkeypatch.setattr(ops, "dw_terms", lambda dw: (dw[:, : dw.shape[1] // 2], dw[:, dw.shape[1] // 2:]))
-    # stage 0: everything within k_max is calibrated
-    g, hi = spec(256)
+    rep_a, out_a = one_pass(0.0)
+    rep_b, out_b = one_pass(1e6)
+    assert [l[-1] for l in rep_a["layers"]] == ["calibrated", "nearest_few_rows", "calibrated", "nearest_long_k", "calibrated"]
+    assert rep_a["layers"] == rep_b["layers"] and rep_a["calibrated"] == 3 and rep_a["nearest"] == 2
+    assert rep_a["nearest_few_rows"] == 1 and rep_a["nearest_long_k"] == 1
+    for (wa, near), (wb, _), lay in zip(out_a, out_b, rep_a["layers"]):
+        assert torch.equal(wa, wb)                            # ... pack the same bits
+        assert torch.equal(wa, near) == (lay[-1] != "calibrated")
+    assert cal.brief_report(rep_a)["layers_digest"] == cal.brief_report(rep_b)["layers_digest"]
+    assert "layers" not in cal.brief_report(rep_a)
+    # a budget aborts; it never degrades
+    cb = cal.CalibratingBackend(_Inner(), time_budget_s=100.0)
+    g, _ = _fake_launch(128)
     cb.tapgemm(g)
-    assert cb.report["calibrated"] == 1 and not hasattr(g.W, "vgen_dw")
-    # stage 1 (past half): long K keeps to-nearest (W_hi untouched), short K is still calibrated
-    now[0] = 1060.0
-    g, hi = spec(256)
-    cb.tapgemm(g)
-    assert cb.report["past_half_budget_long_k"] == 1 and cb.report["nearest"] == 1 and torch.equal(g.W, hi)
-    g, hi = spec(128)
-    cb.tapgemm(g)
-    assert cb.report["calibrated"] == 2 and not hasattr(g.W, "vgen_dw")
-    # stage 2 (past the budget): nothing is calibrated any more
-    now[0] = 1101.0
-    g, hi = spec(128)
-    cb.tapgemm(g)
-    assert cb.report["over_budget"] == 1 and cb.report["nearest"] == 2 and torch.equal(g.W, hi) and not hasattr(g.W, "vgen_dw")
-    assert inner.launched == [False] * 4                     # every launch went out single-pass
+    now[0] += 101.0
+    g, _ = _fake_launch(128)
+    with pytest.raises(cal.CalibrationTimeout):
+        cb.tapgemm(g)
+    assert hasattr(g.W, "vgen_dw")                            # untouched: the caller re-packs
+
+
+def test_a_dead_input_column_keeps_its_weights(monkeypatch):
+    """a column that is zero in the calibration batch may be live later (a temporal tap at F = 1, an
+    absent condition channel) — its weights are rounded to nearest, not zeroed, and the other columns are unaffected by it."""
+    from vgen_amd.calibrate import gptq_round
+    g = torch.Generator("cpu").manual_seed(3)
+    K, N, M = 96, 24, 2048
+    A = torch.randn(M, K, generator=g) @ (torch.randn(K, K, generator=g) * 0.2 + torch.eye(K))
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    A[:, 5] = 0
+    A[:, 40] = 0
+    Q = gptq_round(W, A.t() @ A, torch.float16)
+    assert torch.equal(Q[:, 5], W[:, 5].half()) and torch.equal(Q[:, 40], W[:, 40].half())
+    assert float(Q[:, 5].float().abs().min()) > 0
+    live = [k for k in range(K) if k not in (5, 40)]
+    Q2 = gptq_round(W[:, live], (A.t() @ A)[live][:, live], torch.float16, damp=0.01 * (K - 2) / K)
+    # the same damping constant up to the mean over two fewer columns: the live columns see (almost) the same problem
+    assert float((Q[:, live].float() - Q2.float()).abs().max()) <= 2.0 ** -9 * float(W.abs().max())
+    # every column dead: plain to-nearest
+    assert torch.equal(gptq_round(W, torch.zeros(K, K), torch.float16), W.half())
+
+
+def test_calibration_batch_is_seeded_and_spread_over_the_schedule():
+    from vgen_amd.calibrate import calibration_batch
+    x, t, y = calibration_batch((4, 2, 4, 4), n=8, seed=7)
+    x2, t2, y2 = calibration_batch((4, 2, 4, 4), n=8, seed=7)
+    assert torch.equal(x, x2) and torch.equal(y, y2) and torch.equal(t, t2)
+    assert x.shape == (8, 4, 2, 4, 4) and y.shape == (8, 77, 1024) and t.dtype == torch.long
+    assert t.tolist() == [937, 812, 687, 562, 437, 312, 187, 62]
+
+
+def test_calibrated_weights_persist_and_reload_through_the_constructor(emu_backend, tmp_path):
+    """VERDICT r05 next #1b: calibrate once, save; `precision="calibrated", calibration=<file>` (the yaml route: the
+    registry passes both to the constructor) packs single-pass and loads the file — same packed bits, same output; a file
+    made for other weights is refused; two calibrations of the same model are bit-identical."""
+    from vgen_amd import calibrate as cal
+    from vgen_amd import registry
+    from vgen_amd.unet import UNetSD_T2VBase
+    MODEL = registry.install({"MODEL": registry.Registry("MODEL")})["MODEL"]
+    m, g, sd = _tiny("high")
+    xc, tc, yc = cal.calibration_batch(tuple(g["x"].shape[1:]), n=4, seed=99, context=tuple(g["y"].shape[1:]))
+    rep = cal.calibrate_single_pass(m, xc, tc, y=yc)
+    assert rep["two_term_left"] == 0 and rep["calibration_rows"] == 4
+    out = m(g["x"], g["t"], y=g["y"])
+    dig = cal.packed_digest(m)
+    m_again, _, _ = _tiny("high")
+    cal.calibrate_single_pass(m_again, xc, tc, y=yc)
+    assert cal.packed_digest(m_again) == dig                                  # deterministic
+    path = str(tmp_path / "tiny.cal")
+    head = cal.save_calibrated(m, path)
+    assert head["count"] > 50 and head["report"]["layers"] == rep["layers"]
+    # through the registry, as `UNet: {type: ..., precision: calibrated, calibration: <file>}` would
+    m2 = MODEL.build(dict(type="UNetSD_T2VBase", **g["cfg"], compute_dtype="fp16", precision="calibrated", calibration=path)).eval()
+    assert isinstance(m2, UNetSD_T2VBase)
+    m2.load_state_dict(sd, strict=True)                                       # the engine's order: build, then load weights
+    assert m2.precision == "calibrated" and m2.calibration == path
+    out2 = m2(g["x"], g["t"], y=g["y"])
+    assert cal.packed_digest(m2) == dig and torch.equal(out, out2)
+    assert not any(getattr(w, "vgen_dw", None) is not None for w in cal._packed_tensors(m2))
+    # other weights: refused, not applied
+    sd_b = torch_ref.synth_state_dict(g["shapes"], seed=g["seed"] + 1)
+    m3 = UNetSD_T2VBase(**g["cfg"], compute_dtype="fp16", precision="calibrated", calibration=path).eval()
+    m3.load_state_dict(sd_b, strict=True)
+    with pytest.raises(ValueError, match="not a rounding of this model's weights"):
+        m3(g["x"], g["t"], y=g["y"])
+    # the keyword pair is checked at construction
+    with pytest.raises(ValueError):
+        UNetSD_T2VBase(**g["cfg"], compute_dtype="fp16", precision="calibrated")
+    with pytest.raises(ValueError):
+        UNetSD_T2VBase(**g["cfg"], compute_dtype="fp16", precision="mixed", calibration=path)
+    with pytest.raises(ValueError):
+        cal.save_calibrated(_tiny("high")[0], path)

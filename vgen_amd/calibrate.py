@@ -23,6 +23,20 @@ drops the two-term operand — the launch itself and everything after it already
 `k_max` keep to-nearest rounding (`W_hi` as it is): the 29 long-K convs of the low-resolution levels are 90 % of the
 factorisation cost and a few per cent of the output's weight-rounding sensitivity.
 
+r06 — the pass is a pure function of (weights, calibration input, k_max, rows_per_k, damp):
+  * which launches are calibrated is decided by RULE, per launch, from its own sizes: K <= k_max AND the calibration batch
+    gives it at least `min_rows_per_k` x K operand rows (H = A^T A of fewer rows is rank-deficient; the rounding then fits
+    one sample — ADVICE r05); everything else keeps to-nearest.  No wall clock: `time_budget_s` can only ABORT the pass
+    (CalibrationTimeout), never change a bit of its result.  `report["layers"]` lists every launch with its decision.
+  * the calibration input is a BATCH (`calibration_batch`: 8 noise / prompt draws at 8 timesteps spread over the sampling
+    schedule, one forward): 8 x the operand rows per launch, and H averages over the trajectory instead of one t.
+  * an all-zero input column ("dead": a temporal tap of a one-frame batch, an absent condition channel) is decoupled from
+    the others and its weights are rounded to nearest — they are NOT zeroed (one forward cannot prove a column
+    dead for every later input).
+  * `save_calibrated(model, path)` / `load_calibrated(model, path)` persist the packed 16-bit matrices: a deployment
+    calibrates once; `UNet: {precision: calibrated, calibration: <file>}` in a config reaches `load_calibrated` through the
+    constructor (vgen_amd/unet.py::pack).
+
 This is pack-time work (one forward + ~1 minute of host linear algebra for the 1.4 G-parameter UNet), not part of the hot
 path; nothing here runs inside a denoise step.
 """
@@ -101,10 +115,12 @@ def gptq_round(W: torch.Tensor, H: torch.Tensor, dt, damp: float = 0.01, block: 
     H = H.detach().to(device="cpu", dtype=torch.float64).clone()
     N, K = W.shape
     d = H.diagonal()
-    dead = d <= 0                                   # an input column that is identically zero: its weight cannot matter
-    H[dead, dead] = 1.0
-    W[:, dead] = 0.0
+    # an input column that was identically zero in the calibration batch: its row / column of H is zero, so a unit diagonal
+    # decouples it from the others and its weights come out rounded to nearest — NOT zeroed: one calibration batch cannot
+    # prove the column dead for every later input (a temporal tap at F = 1, an optional condition channel)
+    dead = d <= 0
     mean_d = float(d.mean())
+    H[dead, dead] = mean_d if mean_d > 0 else 1.0
     U = None
     for attempt in range(3):                        # a numerically singular H: more damping; at worst, to-nearest
         H.diagonal().add_(damp * (10.0 ** attempt) * mean_d)
@@ -169,28 +185,40 @@ def gathered_operand(g, rows: torch.Tensor) -> torch.Tensor:
     return torch.cat(parts, 1)
 
 
+class CalibrationTimeout(RuntimeError):
+    """The pass ran past `time_budget_s`.  It aborts — a budget never changes which weights are calibrated (r05 degraded
+    silently: the packed bits then depended on the host's speed)."""
+
+
 class CalibratingBackend:
-    """Wraps an op backend: every tap-GEMM launch whose weight is still two-term gets its weight rounded (error feedback
-    for K <= k_max, to-nearest above) and converted to single-pass IN PLACE before the launch is forwarded."""
+    """Wraps an op backend: every tap-GEMM launch whose weight is still two-term gets its weight rounded and converted to
+    single-pass IN PLACE before the launch is forwarded — by error feedback when the RULE says so, else to nearest:
+
+        K <= k_max   and   rows of the launch (g.M) >= min_rows_per_k * K
+
+    Both are properties of the launch, so the same model + calibration batch always gives the same bits."""
 
     def __init__(self, inner, damp: float = 0.01, k_max: int = 9000, rows_per_k: int = 4, min_rows: int = 16384,
-                 time_budget_s: float = 0.0, k_max_late: int = 3000):
+                 time_budget_s: float = 0.0, min_rows_per_k: float = 2.0):
         self.inner = inner
         self.damp, self.k_max, self.rows_per_k, self.min_rows = damp, k_max, rows_per_k, min_rows
-        # time_budget_s > 0 bounds the pass.  The forward visits the full-resolution level — where the sensitivity sits, all of
-        # it K <= 2880 — first and LAST, and the long-K layers of the low-resolution levels (K = 3840 / 5120 / 5760: two thirds
-        # of the factorisation time, a tenth of the gain: k_max = 3000 alone reads 9.13e-4 on the emulator, 9000 8.36e-4) in
-        # between.  So a pass that has used HALF its budget stops paying for K > k_max_late (those keep to-nearest), and only
-        # a pass that has used all of it leaves everything that follows to-nearest.
-        now = time.time()
-        self.deadline = now + time_budget_s if time_budget_s > 0 else None
-        self.half = now + 0.5 * time_budget_s if time_budget_s > 0 else None
-        self.k_max_late = k_max_late
-        self.report = dict(calibrated=0, nearest=0, over_budget=0, past_half_budget_long_k=0, seconds_h=0.0, seconds_round=0.0,
-                           max_move=0.0)
+        self.min_rows_per_k = min_rows_per_k
+        self.t_start = time.time()
+        self.time_budget_s = time_budget_s
+        self.report = dict(calibrated=0, nearest=0, nearest_long_k=0, nearest_few_rows=0, seconds_h=0.0, seconds_round=0.0,
+                           max_move=0.0, layers=[],
+                           rule=dict(k_max=k_max, min_rows_per_k=min_rows_per_k, rows_per_k=rows_per_k, min_rows=min_rows,
+                                     damp=damp))
 
     def __getattr__(self, name):            # every other op: the wrapped backend's
         return getattr(self.inner, name)
+
+    def decide(self, M: int, K: int) -> str:
+        if K > self.k_max:
+            return "nearest_long_k"
+        if M < self.min_rows_per_k * K:
+            return "nearest_few_rows"
+        return "calibrated"
 
     def tapgemm(self, g):
         dw = getattr(g.W, "vgen_dw", None)
@@ -198,15 +226,12 @@ class CalibratingBackend:
             K = g.taps * g.C1 + g.C2
             dt = g.W.dtype
             assert dw.shape[1] == 2 * K and g.W.shape[1] == K and g.W.is_contiguous()
-            now = time.time()
-            late = self.deadline is not None and now > self.deadline
-            k_lim = self.k_max
-            if late:
-                self.report["over_budget"] += 1
-            elif self.half is not None and now > self.half and self.k_max_late < K <= self.k_max:
-                self.report["past_half_budget_long_k"] += 1
-                k_lim = self.k_max_late
-            if K <= k_lim and g.M > 0 and not late:
+            if self.time_budget_s > 0 and time.time() - self.t_start > self.time_budget_s:
+                raise CalibrationTimeout(f"calibration pass over its budget of {self.time_budget_s:.0f} s after "
+                                         f"{len(self.report['layers'])} weights (nothing is degraded: re-run with a larger "
+                                         f"budget or a smaller k_max)")
+            what = self.decide(g.M, K)
+            if what == "calibrated":
                 t0 = time.time()
                 hi, lo = ops.dw_terms(dw)
                 w32 = hi.float() + lo.float()                                  # the packed fp32 weight to 2^-22
@@ -228,22 +253,49 @@ class CalibratingBackend:
                 self.report["seconds_round"] += time.time() - t1
             else:
                 self.report["nearest"] += 1                                    # W_hi IS the to-nearest rounding
+                self.report[what] += 1
+            self.report["layers"].append((int(g.mode), int(g.M), int(g.N), int(K), what))
             del g.W.vgen_dw
         return self.inner.tapgemm(g)
 
 
+def calibration_units(latent_shape) -> int:
+    """Default size of the calibration batch: 8 units at the t2v latent (16 x 32 x 56 = 28 672 rows per unit at full
+    resolution: the coarsest level then still has 3 584 rows for its K = 1 280 linears), proportionally fewer at larger
+    latents, never fewer than 2 (two timesteps)."""
+    C, F, H, W = latent_shape
+    return max(2, min(8, round(8 * 28672 / float(F * H * W))))
+
+
+def calibration_batch(latent_shape, n: int = None, seed: int = 424242, device="cpu", context=(77, 1024), num_timesteps: int = 1000):
+    """(x [n, C, F, H, W], t [n] long, y [n, L, D]): the default calibration input — n (default calibration_units) seeded
+    noise / prompt draws at n timesteps spread evenly over the sampling schedule (n = 8: t = 937, 812, ..., 62).  Generated on
+    the CPU generator and moved, so the batch — and with it every calibrated bit — is the same on every box.  Family-specific
+    conditioning (image tokens, local images, fps, condition maps) is the caller's to add with the same leading batch size."""
+    C, F, H, W = latent_shape
+    n = calibration_units(latent_shape) if n is None else n
+    gen = torch.Generator("cpu").manual_seed(seed)
+    x = torch.randn(n, C, F, H, W, generator=gen)
+    y = torch.randn(n, context[0], context[1], generator=gen)
+    t = torch.tensor([int(num_timesteps * (2 * (n - i) - 1) / (2 * n)) for i in range(n)], dtype=torch.long)
+    return x.to(device), t.to(device), y.to(device)
+
+
 @torch.no_grad()
-def calibrate_single_pass(model, x, t, damp: float = 0.01, k_max: int = 9000, time_budget_s: float = 0.0, **kwargs):
+def calibrate_single_pass(model, x, t, damp: float = 0.01, k_max: int = 9000, time_budget_s: float = 0.0,
+                          min_rows_per_k: float = 2.0, **kwargs):
     """Turn a model packed with precision="high" into a single-pass model with calibrated roundings, in place.
 
-    x, t, **kwargs: one calibration input for model.forward (any noise / timestep / conditioning of the shapes the model
-    will be sampled at); time_budget_s > 0 bounds the pass (weights reached later keep to-nearest rounding).  Returns the
-    report dict of the pass.  Afterwards `model.precision == "calibrated"`; repacking
-    (loading other weights) returns the model to "high"."""
+    x, t, **kwargs: the calibration input for model.forward — a batch (calibration_batch) of noise / timesteps / conditioning
+    of the shapes the model will be sampled at.  The result is a pure function of the weights, this input and (damp, k_max,
+    min_rows_per_k); time_budget_s > 0 only bounds the pass: over it, CalibrationTimeout is raised and the model must be
+    re-packed (model.invalidate()).  Returns the report dict of the pass (per-launch decisions under "layers").  Afterwards
+    `model.precision == "calibrated"`; save_calibrated() persists the result; repacking (loading other weights) returns the
+    model to "high"."""
     if getattr(model, "precision", None) != "high":
         raise ValueError(f"calibrate_single_pass needs a model built with precision='high' (every packed weight two-term); "
                          f"got precision={getattr(model, 'precision', None)!r}")
-    cb = CalibratingBackend(ops.backend(), damp=damp, k_max=k_max, time_budget_s=time_budget_s)
+    cb = CalibratingBackend(ops.backend(), damp=damp, k_max=k_max, time_budget_s=time_budget_s, min_rows_per_k=min_rows_per_k)
     prev = ops.set_backend(cb)
     # host linear algebra: LAPACK on a few tens of threads (on a 256-thread host the default thread count makes it slower)
     import os
@@ -256,20 +308,102 @@ def calibrate_single_pass(model, x, t, damp: float = 0.01, k_max: int = 9000, ti
         ops.set_backend(prev)
         torch.set_num_threads(threads)
     left = sum(1 for w in _packed_tensors(model) if getattr(w, "vgen_dw", None) is not None)
-    cb.report.update(seconds_total=time.time() - t0, two_term_left=left)
+    cb.report.update(seconds_total=time.time() - t0, two_term_left=left, calibration_rows=int(x.shape[0]))
     model.precision = "calibrated"
+    model.calibration = None                               # in-memory result; save_calibrated() writes it out
     model._epoch = getattr(model, "_epoch", 0) + 1         # sampling sessions key on it: captured graphs are stale
+    model._calibration_report = cb.report
     return cb.report
 
 
-def _packed_tensors(model):
-    def walk(o):
+def _named_packed(model):
+    """(path, tensor) over the model's packed operands, paths like 'input_blocks.1.0/conv1/0'."""
+    def walk(o, path):
         if torch.is_tensor(o):
-            yield o
+            yield path, o
         elif isinstance(o, dict):
-            for v in o.values():
-                yield from walk(v)
+            for k, v in o.items():
+                yield from walk(v, f"{path}/{k}" if path else str(k))
         elif isinstance(o, (tuple, list)):
-            for v in o:
-                yield from walk(v)
-    yield from walk(getattr(model, "_packed", None) or {})
+            for i, v in enumerate(o):
+                yield from walk(v, f"{path}/{i}")
+    yield from walk(getattr(model, "_packed", None) or {}, "")
+
+
+def _packed_tensors(model):
+    for _, w in _named_packed(model):
+        yield w
+
+
+CALIBRATION_FORMAT = 1
+
+
+def brief_report(rep: dict) -> dict:
+    """The report without its per-launch list (for JSON lines): counts + the rule + a digest of the decisions."""
+    import hashlib
+    out = {k: v for k, v in rep.items() if k != "layers"}
+    out["layers_digest"] = hashlib.sha256(repr(rep.get("layers", [])).encode()).hexdigest()[:16]
+    for k in ("seconds_h", "seconds_round", "seconds_total", "max_move"):
+        if k in out:
+            out[k] = round(float(out[k]), 2)
+    return out
+
+
+def packed_digest(model) -> str:
+    """sha256 over the 16-bit packed matrices (path order): two calibrations of the same model must agree on it."""
+    import hashlib
+    h = hashlib.sha256()
+    for path, w in _named_packed(model):
+        if w.dtype in (torch.float16, torch.bfloat16):
+            h.update(path.encode())
+            h.update(w.detach().contiguous().view(torch.int16).cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+def save_calibrated(model, path: str) -> dict:
+    """Write the calibrated 16-bit operands of `model` (precision == "calibrated") to `path` (torch.save of plain tensors
+    keyed by their place in the packed structure + the report).  Returns the header that was written."""
+    if getattr(model, "precision", None) != "calibrated" or getattr(model, "_packed", None) is None:
+        raise ValueError("save_calibrated needs a calibrated, packed model (calibrate_single_pass first)")
+    tensors = {p: w.detach().cpu() for p, w in _named_packed(model) if w.dtype in (torch.float16, torch.bfloat16)}
+    if any(getattr(w, "vgen_dw", None) is not None for w in _packed_tensors(model)):
+        raise ValueError("save_calibrated: a two-term weight is left (the calibration pass did not reach every launch)")
+    head = dict(format=CALIBRATION_FORMAT, model=type(model).__name__, compute_dtype=str(model.compute_dtype),
+                report=getattr(model, "_calibration_report", None), count=len(tensors))
+    torch.save(dict(head=head, tensors=tensors), path)
+    return head
+
+
+@torch.no_grad()
+def load_calibrated(model, path: str, check: bool = True) -> dict:
+    """Replace the 16-bit packed operands of `model` by the calibrated ones in `path`.  The model must be packed single-pass
+    in the calibrated structure (vgen_amd/unet.py::pack does that for precision="calibrated" and calls this).  check: every
+    matrix of the file must lie within a few rounding errors of the to-nearest rounding just packed from the model's OWN
+    weights — a file made for another checkpoint is refused, not applied."""
+    blob = torch.load(path, map_location="cpu", weights_only=False)
+    head, tensors = blob["head"], blob["tensors"]
+    if head.get("format") != CALIBRATION_FORMAT:
+        raise ValueError(f"{path}: calibration format {head.get('format')} != {CALIBRATION_FORMAT}")
+    if head.get("model") != type(model).__name__ or head.get("compute_dtype") != str(model.compute_dtype):
+        raise ValueError(f"{path}: made for {head.get('model')} / {head.get('compute_dtype')}, "
+                         f"not {type(model).__name__} / {model.compute_dtype}")
+    mine = {p: w for p, w in _named_packed(model) if w.dtype in (torch.float16, torch.bfloat16)}
+    if set(mine) != set(tensors):
+        odd = sorted(set(mine) ^ set(tensors))[:4]
+        raise ValueError(f"{path}: packed structure differs ({len(mine)} vs {len(tensors)} matrices; e.g. {odd})")
+    for p, w in mine.items():
+        q = tensors[p]
+        if q.shape != w.shape or q.dtype != w.dtype:
+            raise ValueError(f"{path}: {p} is {tuple(q.shape)} {q.dtype}, the model packs {tuple(w.shape)} {w.dtype}")
+        if getattr(w, "vgen_dw", None) is not None:
+            raise ValueError(f"load_calibrated: {p} is two-term — pack the model with precision='calibrated'")
+        q = q.to(w.device)
+        if check and w.numel():
+            wf, qf = w.float(), q.float()
+            typical = float(wf.pow(2).mean().sqrt()) * (2.0 ** -11 if w.dtype == torch.float16 else 2.0 ** -8)
+            if float((qf - wf).abs().max()) > 64.0 * max(typical, 1e-30):
+                raise ValueError(f"{path}: {p} is not a rounding of this model's weights (calibrated for another checkpoint?)")
+        w.copy_(q)
+    model._calibration_report = head.get("report")
+    model._epoch = getattr(model, "_epoch", 0) + 1
+    return head

@@ -24,5 +24,23 @@ int vgen_check_launch(const char* what) {
   return 0;
 }
 
+// per-device launch state (common.h)
+int vgen_device_slot() {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0;
+  return d < 16 ? d : 15;
+}
+
+int vgen_device_cus() {
+  static int cus[16] = {0};
+  const int d = vgen_device_slot();
+  if (cus[d] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, d) != hipSuccess || n <= 0) n = 256;
+    cus[d] = n;
+  }
+  return cus[d];
+}
+
 extern "C" int vgen_version(void) { return VGEN_ABI_VERSION; }
 extern "C" const char* vgen_last_error(void) { return g_err; }

@@ -202,3 +202,11 @@ int vgen_check_launch(const char* what);
   } while (0)
 
 static inline bool vgen_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+// Per-DEVICE launch state: hipFuncSetAttribute(MaxDynamicSharedMemorySize) is an attribute of the function ON
+// the current device, and the CU count is the device's — a process that drives several GPUs (the in-process unit
+// partition) must not reuse device 0's opt-in or its 256 CUs.  `vgen_device_slot()` = the current device's index into a
+// kernel's `static bool done[VGEN_MAX_DEVICES]`; `vgen_device_cus()` = its multiprocessor count (cached).
+constexpr int VGEN_MAX_DEVICES = 16;
+int vgen_device_slot();
+int vgen_device_cus();

@@ -330,7 +330,8 @@ extern "C" int vgen_linear_f32(const float* x, int32_t n, int32_t K, const float
   VGEN_REQUIRE(act_in == 0 || act_in == 1, "linear_f32: act_in");
   VGEN_REQUIRE(vgen_aligned16(x) && vgen_aligned16(W) && x && W && out, "linear_f32: pointers");
   const size_t lds = (size_t)LIN_R * K * sizeof(float);
-  static bool attr_done = false;
+  static bool attr_done_dev[VGEN_MAX_DEVICES] = {false};
+  bool& attr_done = attr_done_dev[vgen_device_slot()];
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute((const void*)linear_f32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                        LIN_R * 4096 * 4);

@@ -768,7 +768,8 @@ static int groupnorm_impl(const float* x1, int32_t C1, const float* cs1, const f
     const int cpg = C / groups;
     if (nb * S * C * 4 <= fused_max && cpg % 2 == 0 && C1 % 2 == 0 && cpg / 2 <= GNF_THREADS && S * cpg <= GNF_LDS_FLOATS) {
       const size_t lds = (size_t)S * cpg * sizeof(float);
-      static bool attr_done = false;
+      static bool attr_done_dev[VGEN_MAX_DEVICES] = {false};
+      bool& attr_done = attr_done_dev[vgen_device_slot()];
       if (!attr_done) {
         hipError_t e1 = hipFuncSetAttribute((const void*)gn_fused_kernel<BF16>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                             GNF_LDS_FLOATS * 4);

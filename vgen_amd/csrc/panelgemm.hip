@@ -194,7 +194,9 @@ __global__ __launch_bounds__(PANEL_WAVES * 64) void panel_kernel(const vgen_tapg
   const bool res_folded = EPI != EPI_GEGLU16 && p.residual != nullptr;     // GEGLU adds its residual after the gate
 
 #ifdef VGEN_TUNING
-  long long* const stamps = (long long*)p.ws;
+  // the stamp buffer is the caller's workspace, used only when it holds gridDim.x * PANEL_WAVES * 8 int64 (ADVICE r05:
+  // vgen_tapgemm_ws_bytes reports 0 for panel launches, so a split-K workspace of another size may be passed in)
+  long long* const stamps = p.ws_bytes >= (size_t)gridDim.x * PANEL_WAVES * 8 * sizeof(long long) ? (long long*)p.ws : nullptr;
   long long seg[6] = {0, 0, 0, 0, 0, 0};
   long long tprev = stamps ? (long long)__builtin_amdgcn_s_memtime() : 0;
 #endif
@@ -354,18 +356,19 @@ template <typename T, int KS, int BN, bool DW, int EPI>
 int launch_panel(const vgen_tapgemm_args& a, hipStream_t stream) {
   constexpr int LROWS = DW ? 2 * BN : BN;
   constexpr size_t lds = (size_t)(KS / 2) * LROWS * 128 + BN * sizeof(float) + PANEL_WAVES * 3 * 2048;   // panel | bias | A rings
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[VGEN_MAX_DEVICES] = {false};   // the opt-in is per device
+  const int dev = vgen_device_slot();
+  if (!attr_done[dev]) {
     hipError_t e = hipFuncSetAttribute((const void*)panel_kernel<T, KS, BN, DW, EPI>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
       vgen_set_error("tapgemm(panel): hipFuncSetAttribute(%zu B LDS) failed: %s", lds, hipGetErrorString(e));
       return (int)e;
     }
-    attr_done = true;
+    attr_done[dev] = true;
   }
   const int P = a.N / BN;
-  int Cn = 256 / P;                                          // one block per CU: row ranges x panels <= 256
+  int Cn = vgen_device_cus() / P;                            // one block per CU: row ranges x panels <= the device's CUs
   const int nslices = (int)((a.M + SLICE_ROWS - 1) / SLICE_ROWS);
   if (Cn > nslices) Cn = nslices;
   if (Cn < 1) Cn = 1;

@@ -1050,8 +1050,9 @@ Plan make_plan(const vgen_tapgemm_args& a) {
 template <typename T, int BM, int BN, int BK, int WM, int WN, int STAGES, bool PP, bool DW = false>
 int launch(const vgen_tapgemm_args& a, int splitk, hipStream_t stream) {
   constexpr size_t lds = (size_t)STAGES * (BM + BN) * BK * 2;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[VGEN_MAX_DEVICES] = {false};   // the opt-in is per device
+  const int dev = vgen_device_slot();
+  if (!attr_done[dev]) {
     hipError_t e = hipFuncSetAttribute((const void*)tapgemm_kernel<T, BM, BN, BK, WM, WN, STAGES, PP, DW>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) {
@@ -1059,7 +1060,7 @@ int launch(const vgen_tapgemm_args& a, int splitk, hipStream_t stream) {
                      hipGetErrorString(e));
       return (int)e;
     }
-    attr_done = true;
+    attr_done[dev] = true;
   }
   const int64_t tiles_m = (a.M + BM - 1) / BM;
   const int64_t tiles_n = (a.N + BN - 1) / BN;

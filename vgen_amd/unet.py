@@ -283,7 +283,18 @@ class UNetSD_T2VBase(nn.Module):
                 lv[side] = tuple(int(c) for c in digits)
             self.MIXED_LEVELS = {"enc": lv["e"], "mid": lv["m"], "dec": lv["d"], "tx": lv["t"]}
             self.precision = "mixed"
-        assert self.precision in ("fast", "high", "mixed")
+        # "calibrated" (r05/r06, vgen_amd/calibrate.py): every weight ONE 16-bit matrix whose rounding was chosen by error
+        # feedback from a calibration batch.  Either reached in place (build "high", calibrate_single_pass) or from a file
+        # such a pass wrote (save_calibrated): `precision="calibrated", calibration=<path>` — pack() rounds to nearest in the
+        # calibrated structure and load_calibrated() overwrites the matrices, so a config can name the mode:
+        #   UNet: {type: UNetSD_T2VBase, ..., precision: calibrated, calibration: t2v_fp16.cal}
+        self.calibration = kwargs.pop("calibration", None)
+        if self.precision == "calibrated" and not self.calibration:
+            raise ValueError("precision='calibrated' needs calibration=<file written by vgen_amd.calibrate.save_calibrated>; "
+                             "to calibrate a model, build it with precision='high' and call calibrate_single_pass")
+        if self.calibration and self.precision != "calibrated":
+            raise ValueError(f"calibration={self.calibration!r} is only meaningful with precision='calibrated'")
+        assert self.precision in ("fast", "high", "mixed", "calibrated")
         # two-term ACTIVATIONS at the two places where a plain fp32 -> 16-bit cast of a residual-stream tensor is a GEMM
         # operand (attribution, DESIGN §4.1: 0.157 + 0.126 of the 0.758e-6 error energy left once the weights are exact):
         # the raw input of the ResBlock's 1x1 skip conv and the token stream entering proj_out.  On in every mode but
@@ -361,8 +372,11 @@ class UNetSD_T2VBase(nn.Module):
         parameters in place); sampling sessions (vgen_amd/session.py) key on `_epoch`."""
         self._packed = None
         self._epoch = getattr(self, "_epoch", 0) + 1
-        if self.precision == "calibrated":       # vgen_amd/calibrate.py: the calibrated roundings went with the packed
-            self.precision = "high"              # operands; the next pack() is two-term again, ready to be re-calibrated
+        if self.precision == "calibrated" and not getattr(self, "calibration", None):
+            # an in-place calibration (vgen_amd/calibrate.py) went with the packed operands: the next pack() is two-term
+            # again, ready to be re-calibrated.  With a calibration FILE the mode stays: pack() re-applies the file (and
+            # refuses it if the new weights are not the ones it was made for)
+            self.precision = "high"
 
     def _resblocks(self):
         for blk in list(self.input_blocks) + [self.middle_block] + list(self.output_blocks):
@@ -382,7 +396,11 @@ class UNetSD_T2VBase(nn.Module):
     def pack(self, device=None):
         """Build the 16-bit tap-GEMM operands (once per weight load)."""
         with split_weights(self.precision == "high"):
-            return self._pack(device)
+            P = self._pack(device)
+        if self.precision == "calibrated":
+            from .calibrate import load_calibrated
+            load_calibrated(self, self.calibration)
+        return P
 
     # precision="mixed": two-term weights only where the output is most sensitive to the weight rounding.  The rule is
     # structural (module position, not a per-fixture list): rounding errors made early in the encoder at full
@@ -989,7 +1007,8 @@ class UNetSD_SR600(UNetSD_T2VBase):
                          temporal_attn_times=temporal_attn_times, temporal_attention=temporal_attention,
                          use_checkpoint=use_checkpoint, use_image_dataset=use_image_dataset,
                          use_sim_mask=use_sim_mask, inpainting=inpainting, use_fps_condition=False,
-                         compute_dtype=compute_dtype, precision=kwargs.get("precision"))
+                         compute_dtype=compute_dtype, precision=kwargs.get("precision"),
+                         calibration=kwargs.get("calibration"))
 
     @torch.no_grad()
     def forward(self, x, t, y, x_lr=None, fps=None, video_mask=None, focus_present_mask=None,
