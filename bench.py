@@ -618,6 +618,10 @@ def main():
                          "mixed:e0d01t1-style strings select levels (vgen_amd/unet.py)")
     ap.add_argument("--variants", default="fp16/mixed,fp16/high,fp16/fast,bf16/fast",
                     help="other dtype/precision modes timed + parity-checked after the headline mode (t2v, N = 1); '' = none")
+    ap.add_argument("--calibration-file", default=None,
+                    help="--precision calibrated: load the timed model's calibrated weights from this file if it exists, else "
+                         "calibrate and save them there (calibrate.save_calibrated) — profiling passes of one model pay the "
+                         "pack-time pass once")
     ap.add_argument("--stage1", default="text_image", choices=["text_image", "vcomposer"],
                     help="--config tft2v_sr600: composition list of the first stage (vcomposer = the reference yaml's eight "
                          "entries with six pixel-resolution condition maps)")
@@ -722,6 +726,13 @@ def main():
         dist.barrier()
         if rank == 0 and cal_file and os.path.exists(cal_file):
             os.remove(cal_file)
+    elif args.precision == "calibrated" and args.calibration_file:
+        if os.path.exists(args.calibration_file):
+            model = build_model(args.config, dev, args.dtype, "calibrated", state_dict=sd, calibration=args.calibration_file)
+        else:
+            model = build_model(args.config, dev, args.dtype, "calibrated", state_dict=sd)
+            from vgen_amd.calibrate import save_calibrated
+            save_calibrated(model, args.calibration_file)
     else:
         model = build_model(args.config, dev, args.dtype, args.precision, state_dict=sd)
     if args.config == "t2v":

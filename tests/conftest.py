@@ -13,6 +13,12 @@ GOLD = os.path.join(ROOT, "tests", "golden")
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (runs through libvgen_hip.so)")
     config.addinivalue_line("markers", "reference: needs the read-only reference tree (/root/reference)")
+    # CPU suite: a bounded thread count.  The emulator's many small torch ops fork / join on every one of the box's threads
+    # by default; with a second pytest (or any other load) on an 8-core box that oversubscription made one session test take
+    # 9 minutes instead of 9 seconds.  VGEN_TEST_THREADS overrides; GPU boxes keep torch's default
+    # (the calibration pass there sizes its own LAPACK threads).
+    if not torch.cuda.is_available() or os.environ.get("VGEN_TEST_THREADS"):
+        torch.set_num_threads(max(1, int(os.environ.get("VGEN_TEST_THREADS", min(os.cpu_count() or 1, 4)))))
 
 
 def pytest_collection_modifyitems(config, items):

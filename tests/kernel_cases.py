@@ -385,6 +385,44 @@ def tapgemm_cases(dt):
     return c
 
 
+def r06_shape_cases(dt):
+    """name -> (spec, (shape, bn, splitk)): launches forced (through the product ABI's plan table, vgen_tapgemm_set_plans) onto
+    the two r06 shapes of csrc/tapgemm.hip — "pp256" (4: 256 x 256 x 32 ping-pong, 16-bit outputs) and "q128" (5: 4-wave
+    128 x BN x 32, several blocks per CU) — over every epilogue / tap mode / tail they are legal for."""
+    c = {}
+    c["pp256_lin_out16_res"] = (make_tapgemm(dt, 1000, 512, 640, out_dtype=dt, residual=True, seed=21), (4, 256, 1))
+    c["pp256_lin_out16_raggedM_3tiles"] = (make_tapgemm(dt, 777, 768, 320, out_dtype=dt, bias=False, seed=22), (4, 256, 1))
+    c["pp256_geglu"] = (make_tapgemm(dt, 700, 1024, 320, epilogue=L.EPI_GEGLU, out_dtype=dt, seed=23), (4, 256, 1))
+    c["pp256_geglu_res"] = (make_tapgemm(dt, 515, 512, 1280, epilogue=L.EPI_GEGLU, out_dtype=dt, residual=True, seed=24), (4, 256, 1))
+    c["pp256_splitk2_out16"] = (make_tapgemm(dt, 300, 256, 2048, out_dtype=dt, seed=25), (4, 256, 2))
+    c["pp256_geglu_splitk2"] = (make_tapgemm(dt, 260, 512, 1024, epilogue=L.EPI_GEGLU, out_dtype=dt, residual=True, seed=26), (4, 256, 2))
+    c["pp256_temporal_out16"] = (make_tapgemm(dt, 2 * 5 * 24, 256, 128, mode=L.TAP_TEMPORAL3, F=5, S=24, out_dtype=dt, seed=27), (4, 256, 1))
+    c["pp256_views_rowbias"] = (make_tapgemm(dt, 384, 256, 192, a_pad=64, w_pad=128, rowbias=96, out_dtype=dt, seed=28), (4, 256, 1))
+    c["q128_lin_res_b128"] = (make_tapgemm(dt, 896, 1280, 1280, residual=True, seed=31), (5, 128, 1))
+    c["q128_lin_res_b128_sk2"] = (make_tapgemm(dt, 896, 1280, 1280, residual=True, seed=31), (5, 128, 2))
+    c["q128_lin_b160_raggedM"] = (make_tapgemm(dt, 1000, 320, 640, residual=True, seed=32), (5, 160, 1))
+    c["q128_lin_b64_out16"] = (make_tapgemm(dt, 300, 192, 256, out_dtype=dt, seed=33), (5, 64, 1))
+    c["q128_temporal_res_sk3"] = (make_tapgemm(dt, 2 * 16 * 28, 1280, 1280, mode=L.TAP_TEMPORAL3, F=16, S=28, residual=True, seed=34), (5, 128, 3))
+    c["q128_conv_rowbias_b160"] = (make_tapgemm(dt, 32 * 4 * 7, 320, 256, mode=L.TAP_CONV3X3, nimg=32, Hi=4, Wi=7, Ho=4, Wo=7,
+                                                stride=1, pad_t=1, pad_l=1, ups=0, rowbias=16 * 28, seed=35), (5, 160, 1))
+    c["q128_conv_s2_skipseg"] = (make_tapgemm(dt, 2 * 5 * 4, 128, 128, mode=L.TAP_CONV3X3, nimg=2, Hi=10, Wi=8, Ho=5, Wo=4,
+                                              stride=2, pad_t=1, pad_l=1, ups=0, C2=192, seed=36), (5, 128, 1))
+    c["q128_geglu_b128"] = (make_tapgemm(dt, 200, 512, 320, epilogue=L.EPI_GEGLU, out_dtype=dt, residual=True, seed=37), (5, 128, 1))
+    c["q128_geglu_b64"] = (make_tapgemm(dt, 150, 320, 128, epilogue=L.EPI_GEGLU, out_dtype=dt, seed=38), (5, 64, 1))
+    c["q128_colstats_b160"] = (make_tapgemm(dt, 9000, 320, 320, residual=True, colstats=True, seed=39), (5, 160, 1))
+    c["q128_colstats_b128_rowbias"] = (make_tapgemm(dt, 6 * 24 * 20, 128, 64, mode=L.TAP_CONV3X3, nimg=6, Hi=24, Wi=20, Ho=24,
+                                                    Wo=20, rowbias=3 * 24 * 20, colstats=True, seed=40), (5, 128, 1))
+    c["q128_split_out"] = (make_tapgemm(dt, 3000, 640, 2560, out_dtype=dt, residual=True, split_out=True, seed=41), (5, 128, 1))
+    return c
+
+
+def plan_signature(g):
+    """The 9 integers a plan-table row is keyed on (csrc/tapgemm.hip PlanEntry)."""
+    from vgen_amd.ops import _ENUM
+    flags = (1 if g.residual is not None else 0) | (2 if g.rowbias is not None else 0) | (4 if g.colstats else 0)
+    return (g.mode, g.M, g.N, g.C1, g.C2, g.taps, g.epilogue, _ENUM[g.out_dtype], flags)
+
+
 def panel_cases(dt, dualw=False):
     """r05: launches the W-panel-resident shape takes (csrc/panelgemm.hip: linear, K = 320, M >= 2048, N a multiple of the
     panel width) — every epilogue, ragged M (last slice partial, slices not a multiple of the 8 waves or of the row

@@ -301,3 +301,42 @@ def test_splitk_parity_cases_really_split():
             assert a[0].ws_bytes == sk * spec.M * spec.N * 4 and a[1] is None and a[-1] is None, (name, sk, a[0].ws_bytes)
             tiles = -(-spec.M // (128 if shape == SHAPE_PP128 else 256)) * -(-spec.N // bn)
             assert tiles * sk <= 512, (name, tiles, sk)  # split-K exists to FILL the chip, not to oversubscribe it
+
+
+def test_r06_shapes_are_reached_through_the_plan_table_and_only_where_legal():
+    """pp256 (4) / q128 (5) are never proposed by the cost model; a plan-table row puts a launch on them — and is ignored
+    where the shape is not legal (pp256: N % 256 == 0 and a 16-bit output, no column statistics); a table row also takes a
+    K = 320 linear away from the panel shape (csrc/tapgemm.hip full_plan)."""
+    import ctypes as C
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import kernel_cases as kc
+    from vgen_amd import ops
+    be = ops.HipBackend()
+
+    def planned(spec, plan):
+        arr = (C.c_int64 * 12)(*(list(kc.plan_signature(spec)) + list(plan)))
+        try:
+            assert be.lib.vgen_tapgemm_set_plans(arr, 1) == 0
+            return tuple(be.tapgemm_plan(spec))
+        finally:
+            be.lib.vgen_tapgemm_set_plans(None, -1)
+
+    for dt in (torch.float16, torch.bfloat16):
+        for name, (spec, plan) in kc.r06_shape_cases(dt).items():
+            assert tuple(be.tapgemm_plan(spec))[0] not in (4, 5), name          # not without the table
+            assert planned(spec, plan) == plan, name
+            if plan[2] > 1:
+                arr = (C.c_int64 * 12)(*(list(kc.plan_signature(spec)) + list(plan)))
+                be.lib.vgen_tapgemm_set_plans(arr, 1)
+                try:
+                    assert be._tapgemm_args(spec, alloc=False)[0].ws_bytes == plan[2] * spec.M * spec.N * 4, name
+                finally:
+                    be.lib.vgen_tapgemm_set_plans(None, -1)
+        f32 = kc.make_tapgemm(dt, 1000, 512, 640, residual=True)                 # fp32 output: pp256 has no epilogue for it
+        assert planned(f32, (4, 256, 1))[0] != 4
+        n320 = kc.make_tapgemm(dt, 1000, 320, 640, out_dtype=dt)                 # N % 256 != 0
+        assert planned(n320, (4, 256, 1))[0] != 4
+        pan = kc.make_tapgemm(dt, 9000, 2560, 320, epilogue=kc.L.EPI_GEGLU, out_dtype=dt)
+        assert tuple(be.tapgemm_plan(pan))[0] == 3 and planned(pan, (4, 256, 1)) == (4, 256, 1)

@@ -83,6 +83,31 @@ def test_splitk_launches_are_repeatable(hip_backend, dtname):
                 assert torch.equal(out, first[name]), (name, rnd)
 
 
+_R06 = sorted(kc.r06_shape_cases(torch.bfloat16))
+
+
+@pytest.mark.parametrize("dtname", ["bf16", "fp16"])
+@pytest.mark.parametrize("name", _R06)
+def test_tapgemm_r06_shapes(hip_backend, dtname, name):
+    """pp256 / q128 (csrc/tapgemm.hip, r06): the launch is put on the shape by a one-row plan table installed through the
+    PRODUCT ABI (vgen_tapgemm_set_plans — how tools/autotune_gemm.py's measured table reaches make_plan), the planner must
+    confirm it, and the result must match the emulator like every other shape's."""
+    import ctypes as C
+    spec, plan = kc.r06_shape_cases(kc.DTS[dtname])[name]
+    row = list(kc.plan_signature(spec)) + list(plan)
+    arr = (C.c_int64 * 12)(*row)
+    try:
+        assert hip_backend.lib.vgen_tapgemm_set_plans(arr, 1) == 0
+        assert tuple(hip_backend.tapgemm_plan(kc._clone_spec(spec, DEV))) == plan, name
+        res = kc.case_tapgemm(hip_backend, DEV, spec)
+    finally:
+        hip_backend.lib.vgen_tapgemm_set_plans(None, -1)
+    cs = res.pop("colstats", None)
+    _check(res, dtname, out_is_16=spec.out_dtype != torch.float32, tol16=kc.TOL16_EMU)
+    if cs is not None:
+        assert cs["finite"] and cs["rel_l2"] <= 2e-5, cs
+
+
 _TGDW = sorted(kc.tapgemm_dw_cases(torch.bfloat16))
 
 

@@ -16,13 +16,16 @@ if [ -z "${SKIP_SUITE:-}" ]; then
 fi
 if [ -z "${SKIP_SMOKE:-}" ]; then timeout 200 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; tail -4 $O/smoke.log; fi
 cd /tmp && export TMPDIR=/tmp
-PREC=${PREC:-mixed}
-B="python $R/bench.py --precision $PREC --no-graph --no-cpu-baseline --no-vae --no-roofline --no-e2e --no-parity --no-scaling-model --variants="
-timeout 600 python $R/bench.py --steps 20 --warmup 5 --dump-shapes > $O/bench.json 2> $O/bench.err
-cp $R/gpurun_out/tapgemm_shapes_t2v_fp16_mixed.json $R/gpurun_out/other_shapes_t2v_fp16_mixed.json $O/ 2>/dev/null
+PREC=${PREC:-calibrated}
+# the profiled passes load the calibrated weights the bench run below saves (one pack-time pass for all of them)
+CALF=/tmp/vgen_evidence_t2v.cal
+rm -f $CALF
+B="python $R/bench.py --precision $PREC --calibration-file $CALF --no-graph --no-cpu-baseline --no-vae --no-roofline --no-e2e --no-parity --no-scaling-model --variants="
+timeout 900 python $R/bench.py --steps 20 --warmup 5 --dump-shapes --precision $PREC --calibration-file $CALF > $O/bench.json 2> $O/bench.err
+cp $R/gpurun_out/tapgemm_shapes_t2v_fp16_$PREC.json $R/gpurun_out/other_shapes_t2v_fp16_$PREC.json $O/ 2>/dev/null
 tail -c 1500 $O/bench.json
 if [ -z "${SKIP_PARTITION:-}" ]; then
-P="--steps 20 --warmup 5 --no-cpu-baseline --no-vae --no-roofline --no-e2e --no-parity --no-scaling-model --variants= --partition"
+P="--steps 20 --warmup 5 --precision $PREC --calibration-file $CALF --no-cpu-baseline --no-vae --no-roofline --no-e2e --no-parity --no-scaling-model --variants= --partition"
 timeout 200 python $R/bench.py $P > $O/bench_partition_eager.json 2> $O/bench_partition_eager.err
 VGEN_FORCE_COLLECTIVE=1 timeout 200 python $R/bench.py $P > $O/bench_partition_eager_rccl.json 2> $O/bench_partition_eager_rccl.err
 VGEN_FORCE_COLLECTIVE=1 timeout 200 python $R/bench.py $P --graph-collective > $O/bench_partition_graph_rccl.json 2> $O/bench_partition_graph_rccl.err
@@ -51,7 +54,7 @@ for c in "${PASSES[@]:0:${PMC_PASSES:-4}}"; do
   timeout 400 rocprofv3 --pmc $c --output-format csv -d /tmp/prof_$tag -- $B --steps 1 --warmup 1 > /dev/null 2>&1
   f=$(ls /tmp/prof_$tag/*/*counter_collection.csv 2>/dev/null | head -1)
   if [ -n "$f" ]; then SPECS="$SPECS $tag=$f"; else echo "no counter file for $c"; fi
-  python $R/tools/pmc_classes.py $O/pmc_classes.json $SPECS > /dev/null    # after every pass: a call cut short keeps what it has
+  PREC=$PREC python $R/tools/pmc_classes.py $O/pmc_classes.json $SPECS > /dev/null    # after every pass: a call cut short keeps what it has
 done
-python $R/tools/pmc_classes.py $O/pmc_classes.json $SPECS | head -40
+PREC=$PREC python $R/tools/pmc_classes.py $O/pmc_classes.json $SPECS | head -40
 echo EVIDENCE_DONE

@@ -120,7 +120,7 @@ __device__ __forceinline__ int swz_key(int row) {
 // still sitting in registers.  r02 ran this product as a K-doubled launch ([A | A] x [W_hi | W_lo], every A tile
 // gathered, DMA'd and ds_read twice) or, for tap gathers, as two launches through an fp32 temporary.
 template <typename T, int BM, int BN, int BK, int WM, int WN, int STAGES, bool PP, bool DW>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_kernel(
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? ((BM == 128 && BN <= 128) ? 3 : 2) : 1) void tapgemm_kernel(
     const vgen_tapgemm_args p, const int splitk, float* __restrict__ ws, const int ablate_arg) {
   static_assert(!PP || (WM * WN == 8 && STAGES == 3), "ping-pong needs 8 waves and a 3-stage ring");
   static_assert(!DW || (PP && BK == 64), "dual-W K-steps are built on the ping-pong schedule, 64-element K-tiles");
@@ -742,6 +742,9 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_k
     }
     return;
   }
+  // "pp256" (NF = 8, 64 x 128 wave tiles): planned for 16-bit outputs only (legal() below) — the fp32 / column-statistics
+  // epilogue is not instantiated for it (its cs_s / cs_q / bias registers next to 128 accumulators spilled 320 VGPRs)
+  if constexpr (NF > 5) return;
   // column statistics of the final fp32 values per 64-row slab (vgen_tapgemm_args.colstats): the wave
   // tile is 64 ("pp") or 128 ("dual") rows = 1 or 2 whole slabs, so no cross-wave step is needed.
   // Each lane keeps partials over the 4 row fragments of a slab; the 16 lanes that hold different rows
@@ -916,7 +919,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vgen_tapgemm_a
 // small cost model (microseconds; constants fitted to profiles/r01_*_tapgemm_shapes.json):
 //   cost = rounds(tiles * s / slots) * (ceil(KT / s) * t_ktile + t_tile) + [s > 1] * reduce(s)
 // with KT in 64-element K-steps, slots = 256 ("pp", one block per CU) or 512 ("dual").
-enum Shape { SHAPE_PP = 0, SHAPE_DUAL = 1, SHAPE_PP128 = 2, SHAPE_PANEL = 3 };
+// r06 shapes (never proposed by the cost model: reached through the measured plan table / forced plans only):
+//   "pp256" 256 x 256, BK 32, 8 waves (64 x 128 wave tiles), ping-pong, 3 x 32 KiB ring: 128 FLOP per staged byte instead of
+//           85-98 — for the N % 256 == 0 launches with 16-bit outputs (GEGLU up-projections, the K = 1280 q/k/v); 214 VGPRs.
+//   "q128"  128 x BN, BK 32, 4 waves (64 x BN/2 wave tiles), lock-step K-steps, 3 x (128 + BN) x 64 B ring (48-55 KiB):
+//           2-3 INDEPENDENT blocks per CU — for the under-filled 8 x 14 / 4 x 7 levels, where one 8-wave block per CU
+//           leaves every stall of its short K loop uncovered.
+enum Shape { SHAPE_PP = 0, SHAPE_DUAL = 1, SHAPE_PP128 = 2, SHAPE_PANEL = 3, SHAPE_PP256 = 4, SHAPE_Q128 = 5 };
 // r04: 224-row tiles (every row count of the t2v UNet is 7 * 2^k, so 256-row tiles fill the last round over the CUs at
 // most 87.5 %) were built as a dual 224 x BN shape and a 224 x 320 ping-pong shape, passed every parity case they are legal
 // for, and measured +0.5 % (mixed) / +1.4 % (single-pass) SLOWER on the whole step in a same-box A/B
@@ -952,7 +961,8 @@ struct PlanEntry {
 PlanEntry* g_plans = nullptr;
 int g_nplans = -1;
 
-Plan make_plan(const vgen_tapgemm_args& a) {
+Plan make_plan(const vgen_tapgemm_args& a, bool* from_table = nullptr) {
+  if (from_table) *from_table = false;
   const bool geglu = a.epilogue == VGEN_EPI_GEGLU;
   const int KT = a.taps * (a.C1 / 64) + a.C2 / 64;
   const int n_out = geglu ? a.N / 2 : a.N;
@@ -976,9 +986,14 @@ Plan make_plan(const vgen_tapgemm_args& a) {
   auto legal = [&](int shape, int bn, int sk) {
     // BN = 64 is legal for any N as a forced / tabled plan (small-M levels: more, smaller tiles instead of split-K);
     // the cost model itself only proposes it when neither 128 nor 160 divides N
+    if (sk < 1 || sk > (smax < 1 ? 1 : smax)) return false;
+    if (shape == SHAPE_PP256)   // 16-bit outputs through the paired 16-byte stores only (the kernel has no other epilogue)
+      return bn == 256 && a.N % 256 == 0 && vec && a.out_dtype != VGEN_F32 && a.ldo % 8 == 0 && !a.colstats && !a.dualw &&
+             !a.split_out;
     bool ok = bn == 64 && a.N % 64 == 0 && (!geglu || a.N % 64 == 0);
     for (int c = 0; c < nc; ++c) ok |= cands[c] == bn;
-    return ok && shape >= SHAPE_PP && shape <= SHAPE_PP128 && sk >= 1 && sk <= (smax < 1 ? 1 : smax) &&
+    if (shape == SHAPE_Q128) return ok && !a.dualw;
+    return ok && shape >= SHAPE_PP && shape <= SHAPE_PP128 &&
            !(a.colstats && shape == SHAPE_PP128) && !(a.dualw && shape == SHAPE_DUAL);
   };
 #ifdef VGEN_TUNING
@@ -1000,8 +1015,10 @@ Plan make_plan(const vgen_tapgemm_args& a) {
       const PlanEntry& e = tab[i];
       if (e.mode == a.mode && e.M == a.M && e.N == a.N && e.C1 == a.C1 && e.C2 == a.C2 && e.taps == a.taps &&
           e.epilogue == a.epilogue && (e.out_dtype == VGEN_F32) == (a.out_dtype == VGEN_F32) && e.flags == flags &&
-          legal(e.shape, e.bn, e.splitk))   // out_dtype: fp32 vs 16-bit (bf16 and fp16 launches share an entry)
+          legal(e.shape, e.bn, e.splitk)) {   // out_dtype: fp32 vs 16-bit (bf16 and fp16 launches share an entry)
+        if (from_table) *from_table = true;
         return Plan{e.shape, e.bn, e.splitk};
+      }
     }
   }
   Plan best{SHAPE_PP, cands[0], 1};
@@ -1098,10 +1115,20 @@ int panel_bn(const vgen_tapgemm_args& a) {
   return vgen_panel_bn(a);
 }
 
+// The plan of a launch: a measured table entry first (r06: it may also take a K = 320 / 640 linear AWAY from the panel shape),
+// then the panel shape for the launches it takes, then the cost model.
+Plan full_plan(const vgen_tapgemm_args& a) {
+  bool tabled = false;
+  const Plan pl = make_plan(a, &tabled);
+  if (!tabled)
+    if (const int bn = panel_bn(a)) return Plan{SHAPE_PANEL, bn, 1};
+  return pl;
+}
+
 template <typename T>
 int dispatch(const vgen_tapgemm_args& a, hipStream_t s) {
-  if (panel_bn(a)) return vgen_panel_launch(a, s);
-  const Plan pl = make_plan(a);
+  const Plan pl = full_plan(a);
+  if (pl.shape == SHAPE_PANEL) return vgen_panel_launch(a, s);
   if (a.dualw) {
     if (pl.shape == SHAPE_PP128) {
       switch (pl.bn) {
@@ -1114,6 +1141,14 @@ int dispatch(const vgen_tapgemm_args& a, hipStream_t s) {
       case 128: return launch<T, 256, 128, 64, 4, 2, 3, true, true>(a, pl.splitk, s);
       case 160: return launch<T, 256, 160, 64, 4, 2, 3, true, true>(a, pl.splitk, s);
       default: return launch<T, 256, 64, 64, 4, 2, 3, true, true>(a, pl.splitk, s);
+    }
+  }
+  if (pl.shape == SHAPE_PP256) return launch<T, 256, 256, 32, 4, 2, 3, true>(a, pl.splitk, s);
+  if (pl.shape == SHAPE_Q128) {
+    switch (pl.bn) {
+      case 128: return launch<T, 128, 128, 32, 2, 2, 3, false>(a, pl.splitk, s);
+      case 160: return launch<T, 128, 160, 32, 2, 2, 3, false>(a, pl.splitk, s);
+      default: return launch<T, 128, 64, 32, 2, 2, 3, false>(a, pl.splitk, s);
     }
   }
   if (pl.shape == SHAPE_PP) {
@@ -1141,13 +1176,7 @@ int dispatch(const vgen_tapgemm_args& a, hipStream_t s) {
 
 extern "C" int vgen_tapgemm_query_plan(const vgen_tapgemm_args* args, int32_t* out3) {
   if (!args || !out3 || args->N <= 0 || args->M <= 0 || args->C1 <= 0 || args->C1 % 64 || args->C2 % 64) return VGEN_E_BADARG;
-  if (const int bn = panel_bn(*args)) {
-    out3[0] = SHAPE_PANEL;
-    out3[1] = bn;
-    out3[2] = 1;
-    return 0;
-  }
-  const Plan pl = make_plan(*args);
+  const Plan pl = full_plan(*args);
   out3[0] = pl.shape;
   out3[1] = pl.bn;
   out3[2] = pl.splitk;
@@ -1177,8 +1206,7 @@ extern "C" int vgen_tapgemm_set_plans(const int64_t* rows, int32_t n) {
 
 extern "C" size_t vgen_tapgemm_ws_bytes(const vgen_tapgemm_args* args) {
   if (!args || args->N <= 0 || args->M <= 0 || args->C1 <= 0 || args->C1 % 64 || args->C2 % 64) return 0;
-  if (panel_bn(*args)) return 0;
-  const int s = make_plan(*args).splitk;
+  const int s = full_plan(*args).splitk;
   return s > 1 ? (size_t)s * args->M * args->N * sizeof(float) : 0;
 }
 
