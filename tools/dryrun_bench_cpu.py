@@ -1,6 +1,6 @@
 """TEST TOOLING (imports oracle/): runs bench.py's main() END TO END on the CPU, full-size t2v model, with the ABI emulator as
 the op backend — a dry run of the script's host logic (headline measurement, in-run parity, roofline pass, the calibrated
-candidate with its own calibration / timing / roofline / three-fixture parity, headline selection, the JSON line) for code
+model's pack-time calibration, the JSON line; VGEN_DRYRUN_TINY=1: the same on the tiny golden model in about a minute) for code
 paths whose first GPU execution is the driver's.  Nothing here is a measurement: the "times" are the emulator's CPU seconds
 and the fake launch events below; the parity values ARE meaningful (the emulator is within 1 % of the GPU on every fixture
 both have run).  ~20 minutes on 8 cores.
@@ -69,8 +69,28 @@ def main():
     ops.set_backend = lambda b=None: real_set(be if b is None else b)   # bench.py asks for the HIP backend (None): the dry one
     for fn in ("set_device", "synchronize", "empty_cache", "_sleep"):
         setattr(torch.cuda, fn, lambda *a, **k: None)
-    sys.argv = [sys.argv[0], "--steps", "1", "--warmup", "0", "--no-vae", "--no-cpu-baseline", "--no-scaling-model",
-                "--variants", "fp16/calibrated"] + sys.argv[1:]
+    if os.environ.get("VGEN_DRYRUN_TINY") == "1":
+        # host-logic smoke of main() in a minute: the tiny golden model in place of the 1411 M one (no full-size parity)
+        tiny = os.path.join(ROOT, "tests", "golden", "unet_tiny.pt")
+        g = torch.load(tiny, map_location="cpu", weights_only=False)
+        bench.GOLDEN_T2V = tiny
+        bench.CONFIGS["t2v"] = dict(bench.CONFIGS["t2v"], cfg=dict(g["cfg"]), latent=tuple(g["x"].shape[1:]))
+        real_cond = bench.conditioning
+
+        def cond(name, model, P, dev, gen):
+            kw = real_cond(name, model, P, dev, gen)
+            for d in kw:
+                d["y"] = torch.randn(P, g["y"].shape[1], g["y"].shape[2], generator=gen, device=dev)
+            return kw
+        bench.conditioning = cond
+        from vgen_amd import calibrate as cal
+        real_batch = cal.calibration_batch
+        cal.calibration_batch = lambda shape, n=None, **k: real_batch(shape, n=4, **dict(k, context=tuple(g["y"].shape[1:])))
+        sys.argv = [sys.argv[0], "--steps", "2", "--warmup", "1", "--no-vae", "--no-cpu-baseline", "--no-parity",
+                    "--variants", "fp16/mixed,fp16/fast"] + sys.argv[1:]
+    else:
+        sys.argv = [sys.argv[0], "--steps", "1", "--warmup", "0", "--no-vae", "--no-cpu-baseline", "--no-scaling-model",
+                    "--variants", "fp16/mixed"] + sys.argv[1:]
     bench.main()
 
 
