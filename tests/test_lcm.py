@@ -51,3 +51,38 @@ def test_sample_loop_matches_cpu_restatement(emu_backend):
     s.sessions._items["k"] = object()
     s.reset()
     assert not s.sessions._items and s._step_index is None
+
+
+def test_scheduler_matches_hand_derived_known_answers(emu_backend):
+    """a23 pinned to something OUTSIDE this repository's code: tests/golden/lcm_kat.json is computed by
+    tests/golden/make_lcm_kat.py in pure-Python float64 straight from the published formulas — LCM eq. (9) boundary scalings
+    c_skip / c_out (sigma_data 0.5, timestep scaling 10), the skipping-step timestep grid, the scaled-linear betas with the
+    zero-terminal-SNR rescale, the v-parameterised x0 and the multistep update — with no import of torch, vgen_amd or
+    oracle/.  Checked: the 2 / 4 / 8-step timestep lists, alphas_cumprod at six timesteps, the boundary scalings of the four
+    steps, and a whole 4-step loop on a 2 x 2 latent with a fixed model output and fixed step noise."""
+    import json
+    import os
+    from conftest import GOLD
+    from vgen_amd.lcm import LCMScheduler
+    kat = json.load(open(os.path.join(GOLD, "lcm_kat.json")))
+    s = LCMScheduler(prediction_type="v_prediction", beta_schedule="scaled_linear", clip_sample=False,
+                     timestep_spacing="linspace", rescale_betas_zero_snr=True)
+    for n in (2, 4, 8):
+        assert s.set_timesteps(n).tolist() == kat[f"timesteps_{n}"]
+    for t, a in kat["alphas_cumprod"].items():
+        got = float(s.alphas_cumprod[int(t)])                   # fp32 tables, like the package restated
+        assert abs(got - a) <= 3e-6 * max(a, 1e-3) + 1e-9, (t, got, a)
+    for t, (cs, co) in kat["boundary"].items():
+        g_cs, g_co = s.boundary_scalings(int(t))
+        assert abs(g_cs - cs) <= 1e-12 * max(cs, 1e-30) + 1e-18 and abs(g_co - co) <= 1e-12
+    s.set_timesteps(4)
+    x = torch.tensor(kat["x"], dtype=torch.float32).reshape(1, 1, 1, 2, 2)
+    v = torch.tensor(kat["v"], dtype=torch.float32).reshape(1, 1, 1, 2, 2)
+    z = torch.tensor(kat["z"], dtype=torch.float32).reshape(1, 1, 1, 2, 2)
+    s._step_index = None
+    for st in kat["steps"]:
+        prev, den = s.step(v, st["t"], x, return_dict=False, noise=z)
+        for got, want in ((den, st["denoised"]), (prev, st["prev_sample"])):
+            want = torch.tensor(want, dtype=torch.float64).reshape(got.shape)
+            assert float((got.double() - want).abs().max()) <= 2e-6 * float(want.abs().max()), (st["t"], got, want)
+        x = prev

@@ -18,7 +18,10 @@ rescale, clip_sample False) and its call pattern (:179 set_timesteps, :236 scale
 
 The update runs on the device through `vgen_lincomb4` (fp32, no contraction, the operation order written
 above), classifier-free guidance through `vgen_gauss_x0` (u + g * (y - u)); tables are built in fp32 torch
-like the original.  tests/test_lcm.py checks it against the CPU restatement in oracle/torch_ref.py only.
+like the original.  tests/test_lcm.py checks it against the CPU restatement in oracle/torch_ref.py and (r06) against
+known-answer vectors derived by hand from the published formulas in pure-Python float64 (tests/golden/make_lcm_kat.py ->
+lcm_kat.json: timestep lists, alphas_cumprod, boundary scalings, a whole 4-step loop) — pinned to the ALGORITHM; parity
+against the `diffusers` package itself stays unpinned (absent here).
 """
 from __future__ import annotations
 
