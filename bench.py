@@ -220,6 +220,28 @@ def build_model(name, dev, dtype, precision="high", state_dict=None, calibration
     return model
 
 
+def build_vae(dev, dtype, precision, seed=1):
+    """The SD AutoencoderKL on seeded weights in the VAE mode that goes with a UNet precision: "fast" -> to-nearest weights,
+    "calibrated" -> packed two-term and calibrated (calibrate.calibrate_vae: 8 seeded latents / frames of the benchmark's
+    256 x 448 shape through one decode and one encode pass), everything else -> two-term weights ("high")."""
+    from vgen_amd.vae import AutoencoderKL
+    vp = {"fast": "fast", "calibrated": "high"}.get(precision, "high")
+    with torch.device(dev):
+        vae = AutoencoderKL(ddconfig=VAE_SD, embed_dim=4, compute_dtype=dtype, precision=vp)
+    vae.eval()
+    randomize_(vae, seed)
+    if precision == "calibrated":
+        from vgen_amd.calibrate import brief_report, calibrate_vae
+        t0 = time.perf_counter()
+        gen = torch.Generator("cpu").manual_seed(424244)
+        z = (torch.randn(8, 4, 32, 56, generator=gen) / 0.18215 * 0.2).to(dev)
+        x = (torch.rand(8, 3, 256, 448, generator=gen) * 2 - 1).to(dev)
+        rep = brief_report(calibrate_vae(vae, z, x))
+        rep["seconds"] = round(time.perf_counter() - t0, 1)
+        vae.bench_calibration = rep
+    return vae
+
+
 def drop_masters(model, dev):
     """fp32 masters are not needed for sampling once the operands are packed (the variants' condition stems run on
     theirs, so only the t2v trunk drops them)."""
@@ -463,11 +485,7 @@ def run_videolcm(args, dev, model, world, rank):
     sched = LCMScheduler(prediction_type="v_prediction", beta_schedule="scaled_linear", clip_sample=False,
                          timestep_spacing="linspace", rescale_betas_zero_snr=True)
     sched.set_timesteps(4, device=dev)
-    with torch.device(dev):
-        vae = AutoencoderKL(ddconfig=VAE_SD, embed_dim=4, compute_dtype=args.dtype,
-                            precision="fast" if args.precision == "fast" else "high")
-    vae.eval()
-    randomize_(vae, 1)
+    vae = build_vae(dev, args.dtype, args.precision)
     g = torch.Generator(device=dev).manual_seed(8888 + rank)
 
     def one_video():
@@ -522,11 +540,7 @@ def run_two_stage(args, dev, world, rank):
     steps1 = steps2 = 2 if args.steps < 10 else None        # --steps < 10: a 2-step smoke run of every stage
     n1, n2 = steps1 or 50, steps2 or 30
     g = torch.Generator(device=dev).manual_seed(8888 + rank)
-    with torch.device(dev):
-        vae = AutoencoderKL(ddconfig=VAE_SD, embed_dim=4, compute_dtype=args.dtype,
-                            precision="fast" if args.precision == "fast" else "high")
-    vae.eval()
-    randomize_(vae, 1)
+    vae = build_vae(dev, args.dtype, args.precision)
     times = {}
 
     def lap(name, t0):
@@ -918,11 +932,7 @@ def main():
     if rank == 0 and not args.no_vae:
         from vgen_amd.vae import AutoencoderKL
         fh, fw = (int(v) for v in args.vae_size.split("x"))
-        with torch.device(dev):
-            vae = AutoencoderKL(ddconfig=VAE_SD, embed_dim=4, compute_dtype=args.dtype,
-                                precision="fast" if args.precision == "fast" else "high")
-        vae.eval()
-        randomize_(vae, 1)
+        vae = build_vae(dev, args.dtype, args.precision)
         z = torch.randn(2, 4, fh // 8, fw // 8, device=dev) / 0.18215 * 0.2
         for _ in range(2):
             vae.decode(z)
@@ -943,6 +953,8 @@ def main():
                       # error energy would have to go — i.e. nearly all of "high"'s cost.
                       "tolerance": {"bound": "reference fp16-autocast yardstick 1.90e-3", "rel_l2_committed": {
                           "fast": 1.37e-3, "high": 1.03e-3}, "source": "tests/golden/vae_sd_full*.pt via tests/test_gpu_model.py"}}
+        if getattr(vae, "bench_calibration", None) is not None:
+            res["vae"]["calibration"] = vae.bench_calibration
         if args.vae_size == "256x448":
             res["vae"]["tflops_per_s"] = round(fps * VAE_DEC_TFLOP, 2)
             # the 720p frames of BASELINE configs 3 / 5 (SR600 / I2VGen decode and the SR600 stage's encode), 2 frames a call

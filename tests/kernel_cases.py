@@ -398,6 +398,8 @@ def r06_shape_cases(dt):
     c["pp256_geglu_splitk2"] = (make_tapgemm(dt, 260, 512, 1024, epilogue=L.EPI_GEGLU, out_dtype=dt, residual=True, seed=26), (4, 256, 2))
     c["pp256_temporal_out16"] = (make_tapgemm(dt, 2 * 5 * 24, 256, 128, mode=L.TAP_TEMPORAL3, F=5, S=24, out_dtype=dt, seed=27), (4, 256, 1))
     c["pp256_views_rowbias"] = (make_tapgemm(dt, 384, 256, 192, a_pad=64, w_pad=128, rowbias=96, out_dtype=dt, seed=28), (4, 256, 1))
+    c["pp256_f32_res_splitk3_conv"] = (make_tapgemm(dt, 16 * 4 * 7, 1280, 1280, mode=L.TAP_CONV3X3, nimg=16, Hi=4, Wi=7, Ho=4, Wo=7,
+                                                    stride=1, pad_t=1, pad_l=1, ups=0, residual=True, rowbias=28 * 8, seed=29), (4, 256, 3))
     c["q128_lin_res_b128"] = (make_tapgemm(dt, 896, 1280, 1280, residual=True, seed=31), (5, 128, 1))
     c["q128_lin_res_b128_sk2"] = (make_tapgemm(dt, 896, 1280, 1280, residual=True, seed=31), (5, 128, 2))
     c["q128_lin_b160_raggedM"] = (make_tapgemm(dt, 1000, 320, 640, residual=True, seed=32), (5, 160, 1))

@@ -334,8 +334,9 @@ def test_r06_shapes_are_reached_through_the_plan_table_and_only_where_legal():
                     assert be._tapgemm_args(spec, alloc=False)[0].ws_bytes == plan[2] * spec.M * spec.N * 4, name
                 finally:
                     be.lib.vgen_tapgemm_set_plans(None, -1)
-        f32 = kc.make_tapgemm(dt, 1000, 512, 640, residual=True)                 # fp32 output: pp256 has no epilogue for it
+        f32 = kc.make_tapgemm(dt, 1000, 512, 640, residual=True)                 # fp32 output: pp256 has no epilogue for it ...
         assert planned(f32, (4, 256, 1))[0] != 4
+        assert planned(f32, (4, 256, 2)) == (4, 256, 2)                          # ... but the split-K reducer has
         n320 = kc.make_tapgemm(dt, 1000, 320, 640, out_dtype=dt)                 # N % 256 != 0
         assert planned(n320, (4, 256, 1))[0] != 4
         pan = kc.make_tapgemm(dt, 9000, 2560, 320, epilogue=kc.L.EPI_GEGLU, out_dtype=dt)

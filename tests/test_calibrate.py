@@ -301,3 +301,47 @@ def test_calibrated_weights_persist_and_reload_through_the_constructor(emu_backe
         UNetSD_T2VBase(**g["cfg"], compute_dtype="fp16", precision="mixed", calibration=path)
     with pytest.raises(ValueError):
         cal.save_calibrated(_tiny("high")[0], path)
+
+
+def test_vae_calibrates_and_reloads_through_the_constructor(emu_backend, tmp_path):
+    """r06: the AutoencoderKL takes the same route (calibrate_vae: one eager decode + one encode pass): every weight
+    single-pass afterwards, decode / encode between to-nearest ("fast") and two-term ("high") or at two-term's level,
+    deterministic, and `precision="calibrated", calibration=<file>` reproduces the packed bits."""
+    from vgen_amd import calibrate as cal
+    from vgen_amd.vae import AutoencoderKL
+    g = gold("vae_tiny.pt")
+    sd = torch_ref.synth_state_dict(g["shapes"], seed=g["seed"])
+
+    def build(precision, **kw):
+        v = AutoencoderKL(ddconfig=g["ddconfig"], embed_dim=4, compute_dtype="fp16", precision=precision, **kw).eval()
+        v.load_state_dict(sd, strict=True)
+        return v
+
+    errs = {}
+    for prec in ("fast", "high"):
+        v = build(prec)
+        errs[prec] = (rel_l2(v.decode(g["z"]), g["dec"]), rel_l2(v.encode(g["img"]).parameters, g["moments"]))
+    gen = torch.Generator("cpu").manual_seed(77)
+    zc = torch.randn(8, *g["z"].shape[1:], generator=gen) * float(g["z"].std())
+    xc = (torch.rand(8, *g["img"].shape[1:], generator=gen) * 2 - 1)
+    v = build("high")
+    rep = cal.calibrate_vae(v, zc, xc, min_rows_per_k=0.5)
+    # unreached: the two mid-attention V projections — A operands of their product (V^T = Wv a^T), to-nearest in every mode
+    assert v.precision == "calibrated" and rep["calibrated"] > 20 and rep["unreached_to_nearest"] == 2, cal.brief_report(rep)
+    assert not any(getattr(w, "vgen_dw", None) is not None for w in cal._packed_tensors(v))
+    e_dec, e_enc = rel_l2(v.decode(g["z"]), g["dec"]), rel_l2(v.encode(g["img"]).parameters, g["moments"])
+    # the tiny VAE's error is mostly activation rounding: the weight part is what calibration can win back
+    assert e_dec < errs["fast"][0] + 1e-5 and e_enc < errs["fast"][1] + 1e-5, (e_dec, e_enc, errs)
+    v2 = build("high")
+    cal.calibrate_vae(v2, zc, xc, min_rows_per_k=0.5)
+    assert cal.packed_digest(v2) == cal.packed_digest(v)
+    path = str(tmp_path / "vae.cal")
+    cal.save_calibrated(v, path)
+    v3 = build("calibrated", calibration=path)
+    assert torch.equal(v3.decode(g["z"]), v.decode(g["z"])) and cal.packed_digest(v3) == cal.packed_digest(v)
+    # decode-only calibration: the encoder's weights keep to-nearest, nothing stays two-term
+    v4 = build("high")
+    rep4 = cal.calibrate_vae(v4, zc, min_rows_per_k=0.5)
+    assert rep4["unreached_to_nearest"] > 5 and torch.equal(v4.decode(g["z"]), v.decode(g["z"]))
+    with pytest.raises(ValueError):
+        build("calibrated")

@@ -282,16 +282,17 @@ def calibration_batch(latent_shape, n: int = None, seed: int = 424242, device="c
 
 
 @torch.no_grad()
-def calibrate_single_pass(model, x, t, damp: float = 0.01, k_max: int = 9000, time_budget_s: float = 0.0,
-                          min_rows_per_k: float = 2.0, **kwargs):
+def calibrate_single_pass(model, x, t=None, damp: float = 0.01, k_max: int = 9000, time_budget_s: float = 0.0,
+                          min_rows_per_k: float = 2.0, forward=None, **kwargs):
     """Turn a model packed with precision="high" into a single-pass model with calibrated roundings, in place.
 
     x, t, **kwargs: the calibration input for model.forward — a batch (calibration_batch) of noise / timesteps / conditioning
-    of the shapes the model will be sampled at.  The result is a pure function of the weights, this input and (damp, k_max,
-    min_rows_per_k); time_budget_s > 0 only bounds the pass: over it, CalibrationTimeout is raised and the model must be
-    re-packed (model.invalidate()).  Returns the report dict of the pass (per-launch decisions under "layers").  Afterwards
-    `model.precision == "calibrated"`; save_calibrated() persists the result; repacking (loading other weights) returns the
-    model to "high"."""
+    of the shapes the model will be sampled at.  forward: a list of callables run INSTEAD of model(x, t, **kwargs) under the
+    calibrating backend (the AutoencoderKL: its decode and encode passes, calibrate_vae).  The result is a pure function of
+    the weights, this input and (damp, k_max, min_rows_per_k); time_budget_s > 0 only bounds the pass: over it,
+    CalibrationTimeout is raised and the model must be re-packed (model.invalidate()).  Returns the report dict of the pass
+    (per-launch decisions under "layers").  Afterwards `model.precision == "calibrated"`; save_calibrated() persists the
+    result; repacking (loading other weights) returns the model to "high"."""
     if getattr(model, "precision", None) != "high":
         raise ValueError(f"calibrate_single_pass needs a model built with precision='high' (every packed weight two-term); "
                          f"got precision={getattr(model, 'precision', None)!r}")
@@ -303,17 +304,46 @@ def calibrate_single_pass(model, x, t, damp: float = 0.01, k_max: int = 9000, ti
     torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1, 32)))
     t0 = time.time()
     try:
-        model(x, t, **kwargs)
+        if forward is None:
+            model(x, t, **kwargs)
+        else:
+            for fn in forward:
+                fn()
     finally:
         ops.set_backend(prev)
         torch.set_num_threads(threads)
-    left = sum(1 for w in _packed_tensors(model) if getattr(w, "vgen_dw", None) is not None)
-    cb.report.update(seconds_total=time.time() - t0, two_term_left=left, calibration_rows=int(x.shape[0]))
+    # weights no calibration launch reached (a branch the calibration input does not exercise) keep to-nearest rounding
+    unreached = 0
+    for w in _packed_tensors(model):
+        if getattr(w, "vgen_dw", None) is not None:
+            del w.vgen_dw
+            unreached += 1
+    cb.report.update(seconds_total=time.time() - t0, two_term_left=0, unreached_to_nearest=unreached,
+                     calibration_rows=int(x.shape[0]) if torch.is_tensor(x) else None)
     model.precision = "calibrated"
     model.calibration = None                               # in-memory result; save_calibrated() writes it out
     model._epoch = getattr(model, "_epoch", 0) + 1         # sampling sessions key on it: captured graphs are stale
     model._calibration_report = cb.report
     return cb.report
+
+
+@torch.no_grad()
+def calibrate_vae(vae, z, x=None, **opts):
+    """The AutoencoderKL (vgen_amd/vae.py) built with precision="high" -> calibrated single-pass, in place: one eager decode
+    pass over the latents `z` [n, 4, h, w] (already divided by the scale factor, as decode() takes them) and, when `x`
+    [n, 3, H, W] is given, one encode pass — without `x` the encoder's weights keep to-nearest rounding.  Frames are rows
+    here: 8 frames of 256 x 448 give the 32 x 56 level's K = 4608 convs the 2 K rows the rule asks for."""
+    if hasattr(vae, "clear_graphs"):
+        vae.clear_graphs()
+    fns = [lambda: vae._decode_rows(z.float().contiguous())]
+    if x is not None:
+        fns.append(lambda: vae._encode_rows(x.float().contiguous()))
+    if getattr(vae, "_packed", None) is None:
+        vae.pack()
+    rep = calibrate_single_pass(vae, z, forward=fns, **opts)
+    if hasattr(vae, "clear_graphs"):
+        vae.clear_graphs()
+    return rep
 
 
 def _named_packed(model):

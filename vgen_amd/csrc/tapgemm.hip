@@ -987,9 +987,10 @@ Plan make_plan(const vgen_tapgemm_args& a, bool* from_table = nullptr) {
     // BN = 64 is legal for any N as a forced / tabled plan (small-M levels: more, smaller tiles instead of split-K);
     // the cost model itself only proposes it when neither 128 nor 160 divides N
     if (sk < 1 || sk > (smax < 1 ? 1 : smax)) return false;
-    if (shape == SHAPE_PP256)   // 16-bit outputs through the paired 16-byte stores only (the kernel has no other epilogue)
-      return bn == 256 && a.N % 256 == 0 && vec && a.out_dtype != VGEN_F32 && a.ldo % 8 == 0 && !a.colstats && !a.dualw &&
-             !a.split_out;
+    if (shape == SHAPE_PP256)   // its own epilogue: 16-bit outputs through the paired 16-byte stores only; with split-K the
+                                // reducer launch holds the epilogue, so any output the reducer takes is legal
+      return bn == 256 && a.N % 256 == 0 && vec && !a.colstats && !a.dualw && !a.split_out &&
+             (sk > 1 || (a.out_dtype != VGEN_F32 && a.ldo % 8 == 0));
     bool ok = bn == 64 && a.N % 64 == 0 && (!geglu || a.N % 64 == 0);
     for (int c = 0; c < nc; ++c) ok |= cands[c] == bn;
     if (shape == SHAPE_Q128) return ok && !a.dualw;

@@ -173,8 +173,16 @@ class AutoencoderKL(nn.Module):
         self.post_quant_conv = nn.Conv2d(embed_dim, ddconfig["z_channels"], 1)
         self.embed_dim = embed_dim
         self.compute_dtype = ops.sixteen(compute_dtype)
-        self.precision = precision or "fast"      # "high": weights as hi + lo operand pairs (vgen_amd/unet.py)
-        assert self.precision in ("fast", "high")
+        # "high": weights as hi + lo operand pairs (vgen_amd/unet.py); "calibrated" (r06): ONE 16-bit matrix per
+        # layer whose rounding a calibration pass chose (vgen_amd/calibrate.py::calibrate_vae on a "high" model, or
+        # `precision="calibrated", calibration=<file save_calibrated wrote>`): "high"'s accuracy at "fast"'s launches
+        self.precision = precision or "fast"
+        self.calibration = kwargs.pop("calibration", None)
+        if (self.precision == "calibrated") != bool(self.calibration):
+            raise ValueError("AutoencoderKL: precision='calibrated' and calibration=<file> go together (to calibrate a model, "
+                             "build it with precision='high' and call vgen_amd.calibrate.calibrate_vae)")
+        assert self.precision in ("fast", "high", "calibrated")
+        self._epoch = 0
         self._packed = None
         self._attn_qb = None          # query-block override of the mid attention (tests force several blocks)
         self._graphs = collections.OrderedDict()   # (kind, input shape, device) -> captured launch sequence of a chunk (LRU)
@@ -201,6 +209,9 @@ class AutoencoderKL(nn.Module):
 
     def invalidate(self):
         self._packed = None
+        self._epoch = getattr(self, "_epoch", 0) + 1
+        if getattr(self, "precision", None) == "calibrated" and not getattr(self, "calibration", None):
+            self.precision = "high"          # an in-place calibration went with the packed operands (as in the UNets)
         self.clear_graphs()
 
     def clear_graphs(self):
@@ -274,7 +285,11 @@ class AutoencoderKL(nn.Module):
     @torch.no_grad()
     def pack(self):
         with split_weights(self.precision == "high"):
-            return self._pack()
+            P = self._pack()
+        if self.precision == "calibrated":
+            from .calibrate import load_calibrated
+            load_calibrated(self, self.calibration)
+        return P
 
     def _pack(self):
         dt = self.compute_dtype
