@@ -121,7 +121,8 @@ __device__ __forceinline__ int swz_key(int row) {
 // gathered, DMA'd and ds_read twice) or, for tap gathers, as two launches through an fp32 temporary.
 template <typename T, int BM, int BN, int BK, int WM, int WN, int STAGES, bool PP, bool DW>
 __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? ((BM == 128 && BN <= 128) ? 3 : 2) : 1) void tapgemm_kernel(
-    const vgen_tapgemm_args p, const int splitk, float* __restrict__ ws, const int ablate_arg) {
+    const vgen_tapgemm_args p, const int splitk, float* __restrict__ ws, const int ablate_arg, const int stagger,
+    const int first_round) {
   static_assert(!PP || (WM * WN == 8 && STAGES == 3), "ping-pong needs 8 waves and a 3-stage ring");
   static_assert(!DW || (PP && BK == 64), "dual-W K-steps are built on the ping-pong schedule, 64-element K-tiles");
   const int ablate = VGEN_ABLATE_ARG(ablate_arg);
@@ -151,6 +152,20 @@ __global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? ((BM == 128 && BN <= 
   const int lr = lane & 15;  // row within a 16-row fragment
   const int lq = lane >> 4;  // 16-lane group: k-chunk (operands) / 4-row group (C/D)
   const bool w_tail = RBT > 0 && wave * RPI < RBT;
+
+  // ---- start stagger (r06) -------------------------------------------------------------------------------------------
+  // Every block of a launch has the same work, so all CUs reach their epilogues together: the chip's write path (5 - 6.7 TB/s
+  // for all 256 CUs, tools/probes/vmem_probe.hip) sees the launch's stores as one burst per round of tiles while the matrix
+  // pipes idle, then nothing for a K loop (profiles/r02_tapgemm_ablation.json: a launch without its stores is 20 - 37 %
+  // shorter).  Half of the FIRST-round blocks therefore start `stagger` x 1024 cycles late — later rounds inherit the phase
+  // of the slot they fill — so that one half's stores drain under the other half's MFMAs: blocks on odd CUs for the
+  // one-block-per-CU shapes, the block in the odd wave slot of its SIMD for the two-blocks-per-CU ones (HW_REG_HW_ID:
+  // wave_id [3:0], cu_id [11:8]).  Wave 0 decides and sleeps; the others meet it at the first barrier.
+  if (stagger > 0 && (int)(blockIdx.x + gridDim.x * blockIdx.y) < first_round && wave == 0) {
+    const unsigned hw = __builtin_amdgcn_s_getreg((3 << 11) | ((WM * WN == 8 ? 8 : 0) << 6) | 4);   // 4 bits of cu_id / wave_id
+    if (hw & 1u)
+      for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(16);
+  }
 
   // ---- XCD-aware tile renumbering (bijective for any grid size) ----------------------------
   const int tiles_n = (p.N + BN - 1) / BN;
@@ -932,6 +947,12 @@ enum Shape { SHAPE_PP = 0, SHAPE_DUAL = 1, SHAPE_PP128 = 2, SHAPE_PANEL = 3, SHA
 // (profiles/r04a_ab_libs.jsonl); so was the buffer-resource LDS-DMA (+0.1 / +0.6 %).  Both were removed again (history:
 // commits 34443ca, 6b9d39a).
 
+// start stagger of the streaming shapes (see tapgemm_kernel): per cent of one tile's estimated time, by blocks per CU, and the
+// fewest rounds of tiles a launch must have; measured on the whole step (profiles/r06b_ab_stagger.jsonl)
+constexpr int STAGGER_PCT_PP = 0;
+constexpr int STAGGER_PCT_DUAL = 0;
+constexpr int STAGGER_MIN_ROUNDS = 2;
+
 struct Plan {
   int shape;
   int bn;
@@ -1096,8 +1117,33 @@ int launch(const vgen_tapgemm_args& a, int splitk, hipStream_t stream) {
 #else
   const int ablate = 0;
 #endif
+  // start stagger (see the kernel): a fraction of the estimated time of one tile (the cost model's constants), only for
+  // launches with enough rounds of tiles to win it back
+  constexpr int BPC = (WM * WN == 4) ? ((BM == 128 && BN <= 128) ? 3 : 2) : 1;      // co-resident blocks per CU
+  const int cus = vgen_device_cus();
+  int stagger = 0;
+  {
+    int pct = BPC == 1 ? STAGGER_PCT_PP : STAGGER_PCT_DUAL, min_rounds = STAGGER_MIN_ROUNDS;
+#ifdef VGEN_TUNING
+    if (const char* e = getenv("VGEN_TAPGEMM_STAGGER")) {
+      int a1 = 0, a2 = 0, a3 = min_rounds;
+      if (sscanf(e, "%d,%d,%d", &a1, &a2, &a3) >= 2) {
+        pct = BPC == 1 ? a1 : a2;
+        min_rounds = a3;
+      }
+    }
+#endif
+    const int64_t blocks = grid * splitk;
+    const double rounds = (double)blocks / ((double)cus * BPC);
+    if (pct > 0 && rounds >= (double)min_rounds) {
+      const int KT = a.taps * (a.C1 / 64) + a.C2 / 64;
+      const int kts = (KT + splitk - 1) / splitk;
+      const double tile_us = kts * (a.dualw ? 1.6 : 1.0) * (BM == 256 ? (BPC == 1 ? 0.0060 * BN : 0.0150 * BN) : 0.0050 * BN) + 7.0;
+      stagger = (int)(tile_us * pct / 100.0 * 2400.0 / 1024.0 + 0.5);
+    }
+  }
   hipLaunchKernelGGL((tapgemm_kernel<T, BM, BN, BK, WM, WN, STAGES, PP, DW>), dim3((unsigned)grid, (unsigned)splitk),
-                     dim3(WM * WN * 64), lds, stream, a, splitk, (float*)a.ws, ablate);
+                     dim3(WM * WN * 64), lds, stream, a, splitk, (float*)a.ws, ablate, stagger, cus * BPC);
   int rc = vgen_check_launch("tapgemm");
   if (rc || splitk == 1) return rc;
   const int n_out = a.epilogue == VGEN_EPI_GEGLU ? a.N / 2 : a.N;
