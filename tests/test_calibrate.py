@@ -322,18 +322,20 @@ def test_vae_calibrates_and_reloads_through_the_constructor(emu_backend, tmp_pat
         v = build(prec)
         errs[prec] = (rel_l2(v.decode(g["z"]), g["dec"]), rel_l2(v.encode(g["img"]).parameters, g["moments"]))
     gen = torch.Generator("cpu").manual_seed(77)
-    zc = torch.randn(8, *g["z"].shape[1:], generator=gen) * float(g["z"].std())
-    xc = (torch.rand(8, *g["img"].shape[1:], generator=gen) * 2 - 1)
+    zc = torch.randn(24, *g["z"].shape[1:], generator=gen) * float(g["z"].std())
+    xc = (torch.rand(24, *g["img"].shape[1:], generator=gen) * 2 - 1)
     v = build("high")
-    rep = cal.calibrate_vae(v, zc, xc, min_rows_per_k=0.5)
+    rep = cal.calibrate_vae(v, zc, xc)
     # unreached: the two mid-attention V projections — A operands of their product (V^T = Wv a^T), to-nearest in every mode
     assert v.precision == "calibrated" and rep["calibrated"] > 20 and rep["unreached_to_nearest"] == 2, cal.brief_report(rep)
     assert not any(getattr(w, "vgen_dw", None) is not None for w in cal._packed_tensors(v))
     e_dec, e_enc = rel_l2(v.decode(g["z"]), g["dec"]), rel_l2(v.encode(g["img"]).parameters, g["moments"])
-    # the tiny VAE's error is mostly activation rounding: the weight part is what calibration can win back
-    assert e_dec < errs["fast"][0] + 1e-5 and e_enc < errs["fast"][1] + 1e-5, (e_dec, e_enc, errs)
+    # the tiny VAE's error is mostly activation rounding and its launches have few rows per K column: the decode gains a
+    # little, the encode stays where to-nearest is (the full-size decode on the GPU: 1.37e-3 -> 1.13e-3, two-term 1.02e-3)
+    assert e_dec < errs["fast"][0] and e_enc < 1.1 * errs["fast"][1], (e_dec, e_enc, errs)
+    assert errs["high"][0] < e_dec and errs["high"][1] < e_enc
     v2 = build("high")
-    cal.calibrate_vae(v2, zc, xc, min_rows_per_k=0.5)
+    cal.calibrate_vae(v2, zc, xc)
     assert cal.packed_digest(v2) == cal.packed_digest(v)
     path = str(tmp_path / "vae.cal")
     cal.save_calibrated(v, path)
@@ -341,7 +343,7 @@ def test_vae_calibrates_and_reloads_through_the_constructor(emu_backend, tmp_pat
     assert torch.equal(v3.decode(g["z"]), v.decode(g["z"])) and cal.packed_digest(v3) == cal.packed_digest(v)
     # decode-only calibration: the encoder's weights keep to-nearest, nothing stays two-term
     v4 = build("high")
-    rep4 = cal.calibrate_vae(v4, zc, min_rows_per_k=0.5)
+    rep4 = cal.calibrate_vae(v4, zc)
     assert rep4["unreached_to_nearest"] > 5 and torch.equal(v4.decode(g["z"]), v.decode(g["z"]))
     with pytest.raises(ValueError):
         build("calibrated")

@@ -185,6 +185,9 @@ def gathered_operand(g, rows: torch.Tensor) -> torch.Tensor:
     return torch.cat(parts, 1)
 
 
+CALIBRATION_THREADS = 32
+
+
 class CalibrationTimeout(RuntimeError):
     """The pass ran past `time_budget_s`.  It aborts — a budget never changes which weights are calibrated (r05 degraded
     silently: the packed bits then depended on the host's speed)."""
@@ -298,10 +301,15 @@ def calibrate_single_pass(model, x, t=None, damp: float = 0.01, k_max: int = 900
                          f"got precision={getattr(model, 'precision', None)!r}")
     cb = CalibratingBackend(ops.backend(), damp=damp, k_max=k_max, time_budget_s=time_budget_s, min_rows_per_k=min_rows_per_k)
     prev = ops.set_backend(cb)
-    # host linear algebra: LAPACK on a few tens of threads (on a 256-thread host the default thread count makes it slower)
+    # host linear algebra: LAPACK on a FIXED thread count — min(32, the host's CPUs) — whatever the process was started
+    # with.  More threads make it slower on a 256-thread host; fewer make it slow AND change the bits: under
+    # torch.distributed.run (OMP_NUM_THREADS=1 by default) r06's first two-rank run took 247 s instead of 84 s and packed
+    # different (equally good) roundings, because a blocked Cholesky rounds differently per thread count.  With the count
+    # fixed the pass is a pure function of its inputs on a given class of host (profiles/r06_*: the same packed_digest from
+    # the test suite's process and from bench.py's).
     import os
     threads = torch.get_num_threads()
-    torch.set_num_threads(max(1, min(threads, os.cpu_count() or 1, 32)))
+    torch.set_num_threads(max(1, min(os.cpu_count() or 1, CALIBRATION_THREADS)))
     t0 = time.time()
     try:
         if forward is None:
@@ -319,6 +327,7 @@ def calibrate_single_pass(model, x, t=None, damp: float = 0.01, k_max: int = 900
             del w.vgen_dw
             unreached += 1
     cb.report.update(seconds_total=time.time() - t0, two_term_left=0, unreached_to_nearest=unreached,
+                     lapack_threads=max(1, min(os.cpu_count() or 1, CALIBRATION_THREADS)),
                      calibration_rows=int(x.shape[0]) if torch.is_tensor(x) else None)
     model.precision = "calibrated"
     model.calibration = None                               # in-memory result; save_calibrated() writes it out

@@ -949,8 +949,13 @@ enum Shape { SHAPE_PP = 0, SHAPE_DUAL = 1, SHAPE_PP128 = 2, SHAPE_PANEL = 3, SHA
 
 // start stagger of the streaming shapes (see tapgemm_kernel): per cent of one tile's estimated time, by blocks per CU, and the
 // fewest rounds of tiles a launch must have; measured on the whole step (profiles/r06b_ab_stagger.jsonl)
-constexpr int STAGGER_PCT_PP = 0;
-constexpr int STAGGER_PCT_DUAL = 0;
+// r06 call B, one process, 8 settings x 3 interleaved rounds (profiles/r06b_ab_stagger.jsonl, r06b_ab_stagger_shapes.json):
+// whole step 31.50 -> 31.35 ms (-0.5 %) at 50 / 50 / 2; per launch the 3584 x 10240 x 1280 GEGLU -7 %, the 57344 x 320 x 2880
+// conv -5 %, everything else within +-1 %; 100 % of a tile +0.1 %.  Small, free, kept — and a measured answer to "are the
+// epilogue stores a chip-wide burst?": mostly not (a launch without its stores is 20 - 37 % shorter, a launch whose CUs
+// store out of phase 0.5 %): the store path binds per CU, under its own block's idle matrix pipe.
+constexpr int STAGGER_PCT_PP = 50;
+constexpr int STAGGER_PCT_DUAL = 50;
 constexpr int STAGGER_MIN_ROUNDS = 2;
 
 struct Plan {
