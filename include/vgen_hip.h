@@ -192,7 +192,8 @@ size_t vgen_tapgemm_ws_bytes(const vgen_tapgemm_args* args);
 int vgen_tapgemm(const vgen_tapgemm_args* args, void* stream);
 
 /* Tuning introspection (tools/autotune_gemm.py; not needed by callers).  query_plan: the launch plan vgen_tapgemm
- * would use for `args` -> out3 = {block shape (0 pp / 1 dual / 2 pp128 / 3 panel: csrc/panelgemm.hip), BN, split-K}.  set_plans: replace the
+ * would use for `args` -> out3 = {block shape (0 pp / 1 dual / 2 pp128 / 3 panel: csrc/panelgemm.hip / 4 pp256 / 5 q128: r06, reached
+ * through the plan table only), BN, split-K}.  set_plans: replace the
  * measured-plan table consulted before the cost model; rows of 12 int64 {mode, M, N, C1, C2, taps, epilogue,
  * out_dtype, flags (residual | rowbias<<1 | colstats<<2), shape, bn, splitk}; n < 0 restores the compiled-in table. */
 int vgen_tapgemm_query_plan(const vgen_tapgemm_args* args, int32_t* out3);

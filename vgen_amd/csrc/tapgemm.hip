@@ -120,7 +120,7 @@ __device__ __forceinline__ int swz_key(int row) {
 // still sitting in registers.  r02 ran this product as a K-doubled launch ([A | A] x [W_hi | W_lo], every A tile
 // gathered, DMA'd and ds_read twice) or, for tap gathers, as two launches through an fp32 temporary.
 template <typename T, int BM, int BN, int BK, int WM, int WN, int STAGES, bool PP, bool DW>
-__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? ((BM == 128 && BN <= 128) ? 3 : 2) : 1) void tapgemm_kernel(
+__global__ __launch_bounds__(WM* WN * 64, (WM * WN == 4) ? 2 : 1) void tapgemm_kernel(
     const vgen_tapgemm_args p, const int splitk, float* __restrict__ ws, const int ablate_arg, const int stagger,
     const int first_round) {
   static_assert(!PP || (WM * WN == 8 && STAGES == 3), "ping-pong needs 8 waves and a 3-stage ring");
@@ -938,8 +938,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const vgen_tapgemm_a
 //   "pp256" 256 x 256, BK 32, 8 waves (64 x 128 wave tiles), ping-pong, 3 x 32 KiB ring: 128 FLOP per staged byte instead of
 //           85-98 — for the N % 256 == 0 launches with 16-bit outputs (GEGLU up-projections, the K = 1280 q/k/v); 214 VGPRs.
 //   "q128"  128 x BN, BK 32, 4 waves (64 x BN/2 wave tiles), lock-step K-steps, 3 x (128 + BN) x 64 B ring (48-55 KiB):
-//           2-3 INDEPENDENT blocks per CU — for the under-filled 8 x 14 / 4 x 7 levels, where one 8-wave block per CU
-//           leaves every stall of its short K loop uncovered.
+//           2 INDEPENDENT blocks per CU — for the under-filled 8 x 14 / 4 x 7 levels, where one 8-wave block per CU
+//           leaves every stall of its short K loop uncovered.  (Bounded to three blocks per CU the 128 x 128 instance
+//           spilled 16 VGPRs in its epilogue: two, like the dual shape.)
 enum Shape { SHAPE_PP = 0, SHAPE_DUAL = 1, SHAPE_PP128 = 2, SHAPE_PANEL = 3, SHAPE_PP256 = 4, SHAPE_Q128 = 5 };
 // r04: 224-row tiles (every row count of the t2v UNet is 7 * 2^k, so 256-row tiles fill the last round over the CUs at
 // most 87.5 %) were built as a dual 224 x BN shape and a 224 x 320 ping-pong shape, passed every parity case they are legal
@@ -1124,7 +1125,7 @@ int launch(const vgen_tapgemm_args& a, int splitk, hipStream_t stream) {
 #endif
   // start stagger (see the kernel): a fraction of the estimated time of one tile (the cost model's constants), only for
   // launches with enough rounds of tiles to win it back
-  constexpr int BPC = (WM * WN == 4) ? ((BM == 128 && BN <= 128) ? 3 : 2) : 1;      // co-resident blocks per CU
+  constexpr int BPC = (WM * WN == 4) ? 2 : 1;      // co-resident blocks per CU
   const int cus = vgen_device_cus();
   int stagger = 0;
   {
