@@ -42,8 +42,25 @@ def emu_backend():
     from oracle.abi_emulator import EmuBackend
     from vgen_amd import ops
     prev = ops.set_backend(EmuBackend())
+    # ONE thread for everything that runs on the emulator: many of these tests compare two evaluations with different batch
+    # shapes bit for bit (see `one_thread`), the models are tiny (a threaded fork / join per op costs more than it saves), and
+    # a second pytest on the box can no longer oversubscribe the cores
+    n = torch.get_num_threads()
+    torch.set_num_threads(int(os.environ.get("VGEN_EMU_THREADS", "1")))
     yield
+    torch.set_num_threads(n)
     ops.set_backend(prev)
+
+
+@pytest.fixture
+def one_thread():
+    """Bit-level comparisons of two emulator evaluations with DIFFERENT batch shapes (a batch of units vs one forward per
+    unit): a threaded sgemm partitions its K loop by the matrix shape, the last bits of the fp32 sums then differ and a few
+    16-bit roundings downstream flip (1e-3 on the tiny model with 4 threads, 0 with 1, 2 or 8).  One thread: one order."""
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    yield
+    torch.set_num_threads(n)
 
 
 @pytest.fixture

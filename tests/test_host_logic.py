@@ -205,7 +205,7 @@ def test_unet_other_shapes_vs_oracle(emu_backend):
     assert rel_l2(m(x, t, y=y), ref) < 3e-3
 
 
-def test_forward_units_equals_two_forwards(emu_backend):
+def test_forward_units_equals_two_forwards(emu_backend, one_thread):
     m, g, _ = _unet("fp16")
     y2 = torch.roll(g["y"], 1, 0)
     a, b = m.forward_units(g["x"], g["t"], [dict(y=g["y"]), dict(y=y2)])
