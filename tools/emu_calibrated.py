@@ -13,7 +13,7 @@ import torch  # noqa: E402
 import full_cases as fc  # noqa: E402
 from oracle.abi_emulator import EmuBackend  # noqa: E402
 from vgen_amd import ops  # noqa: E402
-from vgen_amd.calibrate import calibrate_single_pass  # noqa: E402
+from vgen_amd.calibrate import brief_report, calibrate_single_pass  # noqa: E402
 
 
 def main():
@@ -29,7 +29,7 @@ def main():
     tc = torch.full_like(g["t"], 637)
     t0 = time.time()
     rep = calibrate_single_pass(m, xc, tc, k_max=k_max, **kwc)
-    print(f"{name}: calibrate_single_pass(k_max={k_max}) on seed 424242 / t = 637: {time.time() - t0:.0f} s  {rep}", flush=True)
+    print(f"{name}: calibrate_single_pass(k_max={k_max}) on seed 424242 / t = 637: {time.time() - t0:.0f} s  {brief_report(rep)}", flush=True)
     fixtures = [(name, g)] + ([("t2v_c", fc.load("t2v_c"))] if name == "t2v" else [])
     for fname, fg in fixtures:
         t0 = time.time()

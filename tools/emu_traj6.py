@@ -16,7 +16,7 @@ import full_cases as fc  # noqa: E402
 from conftest import gold, rel_l2  # noqa: E402
 from oracle.abi_emulator import EmuBackend  # noqa: E402
 from vgen_amd import ops  # noqa: E402
-from vgen_amd.calibrate import calibrate_single_pass  # noqa: E402
+from vgen_amd.calibrate import brief_report, calibrate_single_pass  # noqa: E402
 from vgen_amd.diffusion import DiffusionDDIM  # noqa: E402
 
 
@@ -31,7 +31,7 @@ def main():
         xc, yc = torch.randn(1, 4, 16, 32, 56, generator=cg), torch.randn(1, 77, 1024, generator=cg)
         t0 = time.time()
         rep = calibrate_single_pass(m, xc, torch.tensor([637]), y=yc)
-        print(f"calibrate_single_pass: {time.time() - t0:.0f} s {rep}", flush=True)
+        print(f"calibrate_single_pass: {time.time() - t0:.0f} s {brief_report(rep)}", flush=True)
     gen = torch.Generator("cpu").manual_seed(tr["noise_seed"])
     xt = torch.randn(1, 4, 16, 32, 56, generator=gen)
     y = torch.randn(1, 77, 1024, generator=gen)
