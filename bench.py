@@ -709,10 +709,15 @@ def main():
         dev = torch.device(os.environ["VGEN_BENCH_DEVICE"])
     torch.cuda.set_device(dev)
     if world > 1:
+        # 30 minutes instead of the default 10: the first collective is the hand-off of the calibrated weights — ranks 1 .. N-1
+        # wait in it while rank 0 builds, calibrates (~85 s alone on the host) and saves, with N model builds contending for
+        # the same host cores
+        import datetime
+        pg_timeout = datetime.timedelta(minutes=30)
         if args.backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=pg_timeout)
     elif args.partition and os.environ.get("VGEN_FORCE_COLLECTIVE") == "1":
         # one rank, collectives forced: the partition path's RCCL all-gather really executes on a 1-GPU box (a functional /
         # overhead measurement of the multi-GPU step path, not a scaling number)
