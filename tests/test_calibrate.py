@@ -347,3 +347,57 @@ def test_vae_calibrates_and_reloads_through_the_constructor(emu_backend, tmp_pat
     assert rep4["unreached_to_nearest"] > 5 and torch.equal(v4.decode(g["z"]), v.decode(g["z"]))
     with pytest.raises(ValueError):
         build("calibrated")
+
+
+def test_calibration_auto_is_a_constructor_only_switch(emu_backend, tmp_path, monkeypatch):
+    """r06 ("the drop-in default does not deliver the headline"): `precision="calibrated",
+    calibration="auto"` — what a yaml can say — calibrates the model ITSELF at its first evaluation, on
+    calibrate.calibration_batch at that call's shapes: the same packed bits as the explicit pass on that batch; through a
+    sampling session as well as a plain forward; re-armed by a weight load; `auto:<path>` saves the result and a second
+    model loads the file WITHOUT calibrating."""
+    from vgen_amd import calibrate as cal
+    from vgen_amd.diffusion import DiffusionDDIM
+    from vgen_amd.unet import UNetSD_T2VBase
+    m_ref, g, sd = _tiny("high")
+    shape = tuple(g["x"].shape[1:])
+    xc, tc, yc = cal.calibration_batch(shape, context=tuple(g["y"].shape[1:]))
+    cal.calibrate_single_pass(m_ref, xc, tc, y=yc)
+    dig = cal.packed_digest(m_ref)
+    out_ref = m_ref(g["x"], g["t"], y=g["y"])
+
+    def auto(calibration="auto"):
+        m = UNetSD_T2VBase(**g["cfg"], compute_dtype="fp16", precision="calibrated", calibration=calibration).eval()
+        m.load_state_dict(sd, strict=True)
+        return m
+
+    m = auto()
+    assert m.precision == "high" and m._auto_cal is True and m.calibration is None        # armed, packs two-term
+    out = m(g["x"], g["t"], y=g["y"])                                                      # the first evaluation calibrates
+    assert m.precision == "calibrated" and m._auto_cal is None and m._calibration_report["auto"]
+    assert cal.packed_digest(m) == dig and torch.equal(out, out_ref)
+    ep = m._epoch
+    assert torch.equal(m(g["x"], g["t"], y=g["y"]), out_ref) and m._epoch == ep            # ... once
+    m.load_state_dict(sd, strict=True)                                                     # new weights: armed again
+    assert m.precision == "high" and m._auto_cal is True
+    # through the sampler's session path (SessionCache.get is the entry point there, not forward)
+    m2 = auto()
+    d = DiffusionDDIM(schedule="cosine", schedule_param=dict(num_timesteps=1000, cosine_s=0.008, zero_terminal_snr=True),
+                      mean_type="v", loss_type="mse", var_type="fixed_small", rescale_timesteps=False)
+    kw = [dict(y=g["y"]), dict(y=torch.zeros_like(g["y"]))]
+    xt1, _ = d.ddim_sample(g["x"], g["t"], m2, kw, guide_scale=9.0, ddim_timesteps=50, eta=0.0)
+    assert m2.precision == "calibrated" and cal.packed_digest(m2) == dig
+    d_ref = DiffusionDDIM(schedule="cosine", schedule_param=dict(num_timesteps=1000, cosine_s=0.008, zero_terminal_snr=True),
+                          mean_type="v", loss_type="mse", var_type="fixed_small", rescale_timesteps=False)
+    xt1_ref, _ = d_ref.ddim_sample(g["x"], g["t"], m_ref, kw, guide_scale=9.0, ddim_timesteps=50, eta=0.0)
+    assert torch.equal(xt1, xt1_ref)
+    # auto:<path>: the first model saves, the second loads the file and never calibrates
+    path = str(tmp_path / "auto.cal")
+    m3 = auto("auto:" + path)
+    assert torch.equal(m3(g["x"], g["t"], y=g["y"]), out_ref) and os.path.exists(path) and m3.calibration == path
+    m3.load_state_dict(sd, strict=True)                                                    # a re-pack reloads the file
+    assert m3.precision == "calibrated" and torch.equal(m3(g["x"], g["t"], y=g["y"]), out_ref)
+    m4 = auto("auto:" + path)
+    monkeypatch.setattr(cal, "calibrate_single_pass", lambda *a, **k: (_ for _ in ()).throw(AssertionError("must load, not calibrate")))
+    assert torch.equal(m4(g["x"], g["t"], y=g["y"]), out_ref) and cal.packed_digest(m4) == dig and m4.calibration == path
+    with pytest.raises(ValueError):
+        UNetSD_T2VBase(**g["cfg"], compute_dtype="fp16", precision="mixed", calibration="auto")

@@ -93,3 +93,37 @@ def test_calibrated_single_pass_on_the_other_full_width_fixtures(hip_backend, na
     _record(f"unet_{name}_full/fp16/calibrated", dict(rel_l2=err, norm_ratio=nr, report=_brief(rep)))
     assert err <= NORTH_STAR, err
     assert abs(nr - 1.0) < 5e-3
+
+
+@_SLOW
+def test_calibration_auto_full_size_through_the_public_sampler(hip_backend):
+    """`precision="calibrated", calibration="auto"` at full size, driven only through DiffusionDDIM.ddim_sample (the engine's
+    call): the first step calibrates the model before its session captures anything; afterwards the t = 981 fixture is inside
+    the north-star tolerance and the packed digest is recorded next to the explicit pass's (same batch -> same bits)."""
+    import full_cases as fc
+    from vgen_amd import calibrate as cal
+    from vgen_amd.diffusion import DiffusionDDIM
+    from vgen_amd.unet import UNetSD_T2VBase
+    from oracle import torch_ref
+    g = fc.load("t2v")
+    with torch.device("meta"):
+        m = UNetSD_T2VBase(**g["cfg"], compute_dtype="fp16", precision="calibrated", calibration="auto")
+    m = m.to_empty(device="cpu").eval()
+    m.load_state_dict(torch_ref.synth_state_dict(g["shapes"], seed=g["seed"]), strict=True, assign=True)
+    m = m.to(DEV)
+    assert m.precision == "high" and m._auto_cal is True
+    d = DiffusionDDIM(schedule="cosine", schedule_param=dict(num_timesteps=1000, cosine_s=0.008, zero_terminal_snr=True),
+                      mean_type="v", loss_type="mse", var_type="fixed_small", rescale_timesteps=False)
+    d.rng_parity = False
+    gen = torch.Generator("cpu").manual_seed(5)
+    xt = torch.randn(1, 4, 16, 32, 56, generator=gen).to(DEV)
+    kw = [dict(y=torch.randn(1, 77, 1024, generator=gen).to(DEV)), dict(y=torch.randn(1, 77, 1024, generator=gen).to(DEV))]
+    for step in (981, 961, 941):
+        xt, _ = d.ddim_sample(xt, torch.full((1,), step, dtype=torch.long, device=DEV), m, kw, guide_scale=9.0,
+                              ddim_timesteps=50, eta=0.0)
+    assert m.precision == "calibrated" and m._auto_cal is None and bool(torch.isfinite(xt).all())
+    assert not any(getattr(w, "vgen_dw", None) is not None for w in cal._packed_tensors(m))
+    err, nr = fc.error(fc.forward("t2v", m, g, DEV), g)
+    _record("unet_t2v_full/fp16/calibrated-auto", dict(t2v=err, packed_digest=cal.packed_digest(m),
+                                                        report=_brief(m._calibration_report)))
+    assert err <= NORTH_STAR and abs(nr - 1.0) < 5e-3, err

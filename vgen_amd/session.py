@@ -285,6 +285,8 @@ class SessionCache:
         inner = getattr(model, "module", model)              # DistributedDataParallel wrapper of the engines
         if not hasattr(inner, "_prepare_units") or not hasattr(inner, "_body"):
             return None
+        if getattr(inner, "_auto_cal", None):                 # `calibration: auto`: before anything is packed, staged or
+            inner._maybe_auto_calibrate(tuple(shape), device, kwargs_list[0], t_dtype)      # captured (bumps inner._epoch)
         try:
             kkey = _kw_key(kwargs_list)
         except Unkeyable:

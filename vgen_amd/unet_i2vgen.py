@@ -227,6 +227,7 @@ class UNetSD_I2VGen(UNetSD_T2VBase):
                 focus_present_mask=None, prob_focus_present=0., mask_last_frame_num=0, **kwargs):
         if local_image is None or fps is None:
             raise ValueError("UNetSD_I2VGen.forward needs local_image and fps (unet_i2vgen.py:262-265,298)")
+        self._maybe_auto_calibrate(tuple(x.shape), x.device, dict(y=y, image=image, local_image=local_image, fps=fps), t.dtype)
         B, C, F, H, W = x.shape
         concat, extra = self.condition_stems(local_image, image, B, F, H, W)
         return self._with_stems(x, t, y, concat, extra, fps)

@@ -211,6 +211,7 @@ class _ComposerTrunk(UNetSD_T2VBase):
 
     @torch.no_grad()
     def forward(self, x, t, **kw):
+        self._maybe_auto_calibrate(tuple(x.shape), x.device, kw, t.dtype)
         concat, ctx, per_frame = self._prepare(tuple(x.shape), x.device, **kw)
         return self._trunk(torch.cat([x.float(), concat], 1), t, ctx, kw.get("fps"), ctx_per_frame=per_frame)
 
